@@ -1,0 +1,379 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the IMPORTED REFERENCE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tools/make_golden.py
+
+/root/reference never travels to the GPU box; only the vectors written here do.  Fixtures
+are data (inputs, weights, expected outputs/gradients), never reference source text.
+The reference runs in its native fp64; inputs are fp32-representable so that an fp32
+device path can consume exactly the same numbers.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MANTLE_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, REF)
+import fields  # noqa: E402
+
+# torchvision is not installed; the reference touches it only when blurr=True
+for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.v2"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.modules["torchvision.transforms"].v2 = sys.modules["torchvision.transforms.v2"]
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import symmetric_layers_torch as S  # noqa: E402
+import pytorch_networks_convae as P  # noqa: E402
+import scaler as SC  # noqa: E402
+import multigpu as G  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("pycold", REF + "/.ipynb_checkpoints/pycold-checkpoint.py")
+pycold = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(pycold)
+
+CPU = torch.device("cpu")
+f64 = torch.float64
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(f64)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def randomize_(module, seed):
+    """fp32-representable random parameters (GN affine away from the trivial 1/0)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() == 4:
+                fan = p.shape[1] * p.shape[2] * p.shape[3]
+                p.copy_((torch.randn(p.shape, generator=g) / fan ** 0.5).float().to(p.dtype))
+            elif "layers.1.weight" in n or n.startswith("gn.") and n.endswith("weight"):
+                p.copy_((1.0 + 0.2 * torch.randn(p.shape, generator=g)).float().to(p.dtype))
+            else:
+                p.copy_((0.1 * torch.randn(p.shape, generator=g)).float().to(p.dtype))
+
+
+def sd_np(module, prefix="sd/"):
+    # parameters are fp32-representable by construction -> store them as fp32
+    return {prefix + k: v.detach().float() for k, v in module.state_dict().items()}
+
+
+def grads_np(module, prefix="grad/"):
+    return {prefix + k: p.grad for k, p in module.named_parameters()}
+
+
+# ------------------------------------------------------------------ G1 SymmetricConv2d
+def g1():
+    for tag, (ci, co, k, mode, sym, hw) in {
+        "a": (11, 16, 5, "reflect", {"h": 4, "v": 0, "hv": 0}, (12, 14)),
+        "b": (3, 16, 3, "zeros", {"h": 4, "v": 2, "hv": 4}, (9, 10)),
+        "c": (5, 8, 5, "replicate", {"h": 2, "v": 0, "hv": 0}, (7, 11)),
+    }.items():
+        m = S.SymmetricConv2d(ci, co, k, padding="same", padding_mode=mode, symmetry=sym).double()
+        randomize_(m, 10)
+        x = rnd((2, ci, *hw), 11).requires_grad_(True)
+        y = m(x)
+        ct = rnd(y.shape, 12)
+        (y * ct).sum().backward()
+        npz(f"g1{tag}_symconv", x=x, w=m.weight, b=m.bias, y=y, ct=ct, dx=x.grad, dw=m.weight.grad,
+            db=m.bias.grad, meta=np.array([ci, co, k, sym["h"], sym["v"], sym["hv"]]),
+            mode=np.array(mode))
+
+
+# ------------------------------------------------------------------ G2 FluidLayer
+def g2():
+    for tag, (ci, co, k, act, mode, symm, hw) in {
+        "a": (16, 16, 5, "gelu", "reflect", True, (10, 12)),
+        "b": (8, 4, 3, "selu", "zeros", True, (8, 8)),
+        "c": (6, 8, 5, "relu", "replicate", False, (9, 13)),
+        "d": (8, 8, 3, "silu", "reflect", True, (8, 9)),
+        "e": (8, 8, 3, "tanh", "reflect", False, (8, 9)),
+        "f": (8, 8, 3, "elu", "zeros", False, (8, 9)),
+    }.items():
+        m = P.FluidLayer(ci, co, act, mode, symm, 1, f=k).double()
+        randomize_(m, 20)
+        x = rnd((2, ci, *hw), 21).requires_grad_(True)
+        y = m(x)
+        ct = rnd(y.shape, 22)
+        (y * ct).sum().backward()
+        npz(f"g2{tag}_fluidlayer", x=x, y=y, ct=ct, dx=x.grad, meta=np.array([ci, co, k, int(symm)]),
+            act=np.array(act), mode=np.array(mode), **sd_np(m), **grads_np(m))
+
+
+# ------------------------------------------------------------------ G3 resampling ops
+def g3():
+    x = rnd((1, 2, 31, 32), 30).requires_grad_(True)
+    y = torch.nn.Upsample(size=(63, 64), mode="bicubic")(x)
+    ct = rnd(y.shape, 31)
+    (y * ct).sum().backward()
+    npz("g3a_bicubic_size", x=x, y=y, ct=ct, dx=x.grad)
+    x = rnd((2, 3, 8, 8), 32).requires_grad_(True)
+    y = torch.nn.Upsample(scale_factor=4, mode="bicubic")(x)
+    ct = rnd(y.shape, 33)
+    (y * ct).sum().backward()
+    npz("g3b_bicubic_x4", x=x, y=y, ct=ct, dx=x.grad)
+    x = rnd((2, 3, 13, 17), 34).requires_grad_(True)
+    y = torch.nn.AvgPool2d((2, 2), stride=2)(x)
+    ct = rnd(y.shape, 35)
+    (y * ct).sum().backward()
+    npz("g3c_avgpool2", x=x, y=y, ct=ct, dx=x.grad)
+    x = rnd((1, 2, 16, 12), 36).requires_grad_(True)
+    y = torch.nn.AvgPool2d((4, 4), stride=4)(x)
+    ct = rnd(y.shape, 37)
+    (y * ct).sum().backward()
+    npz("g3d_avgpool4", x=x, y=y, ct=ct, dx=x.grad)
+
+
+# ------------------------------------------------------------------ G4 tiny Unet
+def g4():
+    for tag, (loss_type, p_pred, c_i, c_o, r_p, symm, act) in {
+        "curl": ("curl", True, 10, 3, "reflect", True, "gelu"),
+        "mae": ("mae", True, 11, 4, "reflect", True, "gelu"),
+        "mass_rep": ("mass", False, 10, 3, "replicate", False, "gelu"),
+        "mae_zeros": ("mae", True, 11, 4, "zeros", True, "silu"),
+    }.items():
+        m = P.Unet(3, c_i, 8, c_o, CPU, act, r_p, loss_type, use_symm=symm, repeats=2, f=5,
+                   p_pred=p_pred).double()
+        randomize_(m, 40)
+        x = torch.from_numpy(fields.unet_input(2, 40, 54, 41, c_i=c_i)).requires_grad_(True)
+        outs = m(x)
+        names = ["u", "v", "p", "T"]
+        loss = 0.0
+        save = {}
+        for n, o in zip(names, outs):
+            if o is None:
+                continue
+            ct = rnd(o.shape, 42 + len(save))
+            loss = loss + (o * ct).sum()
+            save["out/" + n] = o
+            save["ct/" + n] = ct
+        loss.backward()
+        # x is regenerated in the tests from fields.unet_input(2, 40, 54, 41, c_i)
+        npz(f"g4_unet_{tag}", dx_sample=fields.strided_sample(x.grad.numpy(), 1021), cfg=np.array([3, c_i, 8, c_o, 2, 5, int(p_pred), int(symm)]),
+            loss_type=np.array(loss_type), r_p=np.array(r_p), act=np.array(act), **save, **sd_np(m),
+            **grads_np(m))
+
+
+# ------------------------------------------------------------------ G5 tiny ConvAE
+def g5():
+    for tag, (loss_type, p_pred, c_i, c_o, r_p, symm) in {
+        "mae": ("mae", True, 3, 3, "reflect", True),
+        "curl": ("curl", True, 3, 3, "zeros", False),
+    }.items():
+        m = pycold.ConvAE(2, c_i, 4, c_o, CPU, "gelu", r_p, loss_type, use_symm=symm, repeats=2, f=3,
+                          p_pred=p_pred).double()
+        randomize_(m, 50)
+        x = rnd((2, c_i, 32, 48), 51).requires_grad_(True)
+        y = m(x)
+        ct = rnd(y.shape, 52)
+        (y * ct).sum().backward()
+        npz(f"g5_convae_{tag}", x=x, y=y, ct=ct, dx=x.grad,
+            cfg=np.array([2, c_i, 4, c_o, 2, 3, int(p_pred), int(symm)]), loss_type=np.array(loss_type),
+            r_p=np.array(r_p), **sd_np(m), **grads_np(m))
+
+
+# ------------------------------------------------------------------ G6 Trainer.loss_fn / get_loss
+class _Stub(torch.nn.Module):
+    """Stands in for model_uvp: returns fixed leaf predictions [B,H,W] (3-D, as the curl
+    head emits them), so get_loss's arithmetic is exercised without the 128x506-only nets."""
+
+    def __init__(self, u, v, p, T):
+        super().__init__()
+        self.u, self.v, self.p, self.T = u, v, p, T
+
+    def forward(self, _):
+        return self.u, self.v, self.p, self.T
+
+
+def _trainer_ns(model, p_pred, loss_scale, loss_derivative, loss_type):
+    ns = types.SimpleNamespace(
+        net="unet", p_pred=p_pred, model_AD=None, loss_scale=loss_scale, loss_derivative=loss_derivative,
+        roll_forward=1, loss_type=loss_type, l1=torch.nn.L1Loss(), model_uvp=model,
+        dx_center_kernel=torch.tensor([-0.5, 0, 0.5]).double().view(1, 1, 1, 3),
+        dy_center_kernel=torch.tensor([-0.5, 0, 0.5]).double().view(1, 1, 3, 1),
+        dx_left_kernel=torch.tensor([-1.0, 1, 0]).double().view(1, 1, 1, 3),
+        dy_top_kernel=torch.tensor([-1.0, 1, 0]).double().view(1, 1, 3, 1))
+    ns.loss_fn = lambda a, b: G.Trainer.loss_fn(ns, a, b)
+    return ns
+
+
+def g6():
+    B, H, W = 2, 128, 506
+    rows = []
+    samples = {}
+    case = 0
+    for p_pred in (True, False):
+        for loss_type in ("mae", "mass", "curl"):
+            for loss_scale in (False, True):
+                for loss_derivative in (False, True):
+                    seed = 600 + case
+                    u = torch.from_numpy(fields.smooth_field(B, H, W, seed + 1, noise=0.01)).requires_grad_(True)
+                    v = torch.from_numpy(fields.smooth_field(B, H, W, seed + 2, noise=0.01)).requires_grad_(True)
+                    p = torch.from_numpy(fields.smooth_field(B, H, W, seed + 3, amp=0.5)).requires_grad_(True)
+                    T = torch.from_numpy(fields.temperature_field(B, H, W, seed + 4)).requires_grad_(True)
+                    truth = [fields.smooth_field(B, H, W, seed + 5), fields.smooth_field(B, H, W, seed + 6)]
+                    if p_pred:
+                        truth.append(fields.smooth_field(B, H, W, seed + 7, amp=0.5))
+                    truth.append(fields.temperature_field(B, H, W, seed + 8))
+                    uvp = torch.from_numpy(np.stack(truth, 1))
+                    c_i = 11 if p_pred else 10
+                    gVTp = torch.from_numpy(fields.unet_input(B, H, W, seed, c_i=c_i))
+                    ns = _trainer_ns(_Stub(u, v, p if p_pred else None, T), p_pred, loss_scale,
+                                     loss_derivative, loss_type)
+                    out = G.Trainer.get_loss(ns, gVTp, uvp, None, None, None)
+                    out[0].backward()
+                    rows.append([int(p_pred), {"mae": 0, "mass": 1, "curl": 2}[loss_type], int(loss_scale),
+                                 int(loss_derivative), seed] + [float(o) for o in out])
+                    samples[f"du/{case}"] = fields.strided_sample(u.grad.numpy())
+                    samples[f"dv/{case}"] = fields.strided_sample(v.grad.numpy())
+                    samples[f"dT/{case}"] = fields.strided_sample(T.grad.numpy())
+                    if p_pred:
+                        samples[f"dp/{case}"] = fields.strided_sample(p.grad.numpy())
+                    case += 1
+    npz("g6_get_loss", table=np.array(rows), **samples)
+    # loss_fn alone on a small field
+    xt = rnd((3, 9, 11), 690)
+    xp = rnd((3, 9, 11), 691)
+    o = {}
+    for ls in (False, True):
+        ns = types.SimpleNamespace(loss_scale=ls, l1=torch.nn.L1Loss())
+        a, b = G.Trainer.loss_fn(ns, xt, xp)
+        o[f"scaled_{int(ls)}"] = a
+        o[f"plain_{int(ls)}"] = b
+    npz("g6b_loss_fn", x_true=xt, x_pred=xp, **o)
+
+
+# ------------------------------------------------------------------ G7..G9 helpers
+def g7():
+    B, H, W = 2, 128, 506
+    u = torch.from_numpy(fields.smooth_field(B, H, W, 700, noise=0.01))
+    v = torch.from_numpy(fields.smooth_field(B, H, W, 701, noise=0.01))
+    o = {}
+    for bc in (False, True):
+        m = P.get_mass(u, v, bc=bc)
+        o[f"sample_bc{int(bc)}"] = fields.strided_sample(m.numpy())
+        o[f"sum_bc{int(bc)}"] = m.sum()
+        o[f"abssum_bc{int(bc)}"] = m.abs().sum()
+        o[f"edge_bc{int(bc)}"] = m[0, 0, :, 0]
+    npz("g7_get_mass", **o)
+
+
+def g8():
+    ramp = (torch.arange(42, dtype=f64).view(1, 1, 6, 7) ** 1.5 + torch.arange(7, dtype=f64) * 0.25)
+    o = {"x": ramp}
+    for name in ("dx_right", "dx_left", "dy_bot", "dy_top", "dx_center", "dy_center", "du_dy", "dv_dx",
+                 "laplace"):
+        o[name] = getattr(P, name)(ramp, CPU)
+    npz("g8_fd_kernels", **o)
+
+
+def g9():
+    T = rnd((2, 1, 5, 6), 900).abs()
+    z = rnd((1, 5, 6), 901).abs()
+    gamma = torch.tensor(86422511.6, dtype=f64)
+    beta = torch.tensor(3.01635241, dtype=f64)
+    eta = P.eta_torch(gamma, beta, z, T)
+    u, v, p = rnd((2, 1, 4, 5), 902), rnd((2, 1, 4, 5), 903), rnd((2, 1, 4, 5), 904)
+    pu, pv, pp = P.pad_uvp(u.clone(), v.clone(), p.clone())
+    g = rnd((1, 2, 4, 5), 905)
+    pg = P.pad_grad(g, (1, 2, 1, 2))
+    ones = np.ones((2, 3))
+    sv = SC.scale_var(ones.copy(), 4.21479129, 86422511.6, 3.01635241, "uprev")
+    uv = SC.unscale_var(ones.copy(), 4.21479129, 86422511.6, 3.01635241, "vprev")
+    pid = SC.scale_var(ones.copy(), 4.21479129, 86422511.6, 3.01635241, "pprev")
+    npz("g9_helpers", T=T, z=z, gamma=gamma, beta=beta, eta=eta, u=u, v=v, p=p, pu=pu, pv=pv, pp=pp, g=g, pg=pg,
+        scale_u=sv, unscale_v=uv, scale_p=pid)
+
+
+def g10():
+    n_newfluid = P.count_parameters(P.NewFluidNet(5, 7, 64, 1, CPU, "gelu", "zeros", "curl", use_symm=False,
+                                                  a_bound=10, repeats=4, f=5, p_pred=False, factor=2))
+    n_cfg2 = P.count_parameters(P.Unet(5, 11, 16, 4, CPU, "gelu", "reflect", "mae", use_symm=True, repeats=3,
+                                       f=5, p_pred=True))
+    n_cfg1 = P.count_parameters(pycold.ConvAE(2, 3, 16, 3, CPU, "gelu", "reflect", "mae", use_symm=True,
+                                              repeats=2, f=3, p_pred=True))
+    n_cfg1_plain = P.count_parameters(pycold.ConvAE(2, 3, 16, 3, CPU, "gelu", "reflect", "mae", use_symm=False,
+                                                    repeats=2, f=3, p_pred=True))
+    m = P.Unet(5, 11, 16, 4, CPU, "gelu", "reflect", "mae", use_symm=True, repeats=3, f=5, p_pred=True)
+    keys = list(m.state_dict().keys())
+    shapes = [tuple(v.shape) for v in m.state_dict().values()]
+    c = pycold.ConvAE(2, 3, 16, 3, CPU, "gelu", "reflect", "mae", use_symm=True, repeats=2, f=3, p_pred=True)
+    npz("g10_known_answers", newfluidnet=n_newfluid, unet_cfg2=n_cfg2, convae_cfg1=n_cfg1,
+        convae_cfg1_plain=n_cfg1_plain, unet_keys=np.array(keys),
+        unet_shapes=np.array([",".join(map(str, s)) for s in shapes]),
+        convae_keys=np.array(list(c.state_dict().keys())),
+        convae_shapes=np.array([",".join(map(str, tuple(v.shape))) for v in c.state_dict().values()]))
+
+
+# ------------------------------------------------------------------ G11 two full training steps
+def g11():
+    """zero_grad -> get_loss -> backward -> Adam.step (multigpu.py:307-320, 761-763) twice on a
+    tiny Unet at the reference's native 128x506 grid, fp64."""
+    B, H, W = 2, 128, 506
+    for tag, (loss_type, p_pred, c_i, c_o, ls, ld) in {
+        # c_i = 10 even with p_pred: get_loss always rebuilds a 10-channel input (multigpu.py:234-248)
+        "mass": ("mass", True, 10, 4, False, False),
+        "curl": ("curl", False, 10, 2, True, True),
+    }.items():
+        m = P.Unet(3, c_i, 8, c_o, CPU, "gelu", "reflect", loss_type, use_symm=True, repeats=2, f=5,
+                   p_pred=p_pred).double()
+        randomize_(m, 110)
+        sd0 = {("sd0/" + k): v.clone().float() for k, v in m.state_dict().items()}
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0)
+        ns = _trainer_ns(m, p_pred, ls, ld, loss_type)
+        losses = []
+        for step in range(2):
+            # get_loss splits 11 channels when p_pred (multigpu.py:198-201) but feeds the net 10
+            gVTp = torch.from_numpy(fields.unet_input(B, H, W, 1100 + step, c_i=11 if p_pred else 10))
+            truth = [fields.smooth_field(B, H, W, 1150 + step), fields.smooth_field(B, H, W, 1160 + step)]
+            if p_pred:
+                truth.append(fields.smooth_field(B, H, W, 1170 + step, amp=0.5))
+            truth.append(fields.temperature_field(B, H, W, 1180 + step))
+            uvp = torch.from_numpy(np.stack(truth, 1))
+            if loss_type != "curl":
+                # feed 3-D predictions like the curl head does (Appendix A.6 broadcast defect otherwise)
+                inner = m
+
+                class Sq(torch.nn.Module):
+                    def forward(self, x):
+                        u, v, p, T = inner(x)
+                        return u[:, 0], v[:, 0], (p[:, 0] if p is not None else None), T[:, 0]
+                ns.model_uvp = Sq()
+            opt.zero_grad()
+            out = G.Trainer.get_loss(ns, gVTp, uvp, None, None, None)
+            out[0].backward()
+            if step == 0:
+                g0 = {("grad0/" + k): p.grad.clone() for k, p in m.named_parameters()}
+            opt.step()
+            losses.append([float(o) for o in out])
+        sd2 = {("sd2/" + k): v for k, v in m.state_dict().items()}
+        npz(f"g11_train_{tag}", losses=np.array(losses),
+            cfg=np.array([3, c_i, 8, c_o, 2, 5, int(p_pred), 1, int(ls), int(ld)]),
+            loss_type=np.array(loss_type), **sd0, **g0, **sd2)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+        fn()
