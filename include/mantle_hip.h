@@ -1,0 +1,218 @@
+/*
+ * mantle_hip.h — C ABI of libmantle_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the Stokes-surrogate training hot path of
+ * agsiddhant/PBML_Mantle_Convection.  The reference has no FFI / operator registry: its
+ * boundary is the Python surface, whose numeric back end is PyTorch ATen.
+ * Every entry point below replaces the ATen call sequence of one reference call site
+ * (cited per function, paths relative to the reference tree).  Host code (Python, ctypes)
+ * mirrors the reference's module/trainer API on top of these.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  `stream` is a hipStream_t
+ *    passed as void*.  All calls are asynchronous on `stream`, stateless and re-entrant.
+ *  - The caller owns every buffer (including workspaces); the library never allocates,
+ *    frees or retains device memory.
+ *  - Return 0 on success; MC_E* (negative) for argument/shape/unsupported errors;
+ *    positive values are hipError_t codes from the launch.  Nothing throws or aborts.
+ *  - Activations use the CB8 layout: [N][C8][H][W][8] with C8 = ceil(C/8) channel blocks,
+ *    element type f32 (MC_F32) or bf16 (MC_BF16).  Padded channels hold zeros.
+ *    Network inputs/outputs and loss fields are plain NCHW / NHW f32.
+ *  - Parameters are read in the REFERENCE's layout (unique mirrored-filter bank
+ *    [U][C_in][k][k] f32, bias [C_out] f32; symmetric_layers_torch.py:96-107).
+ */
+#ifndef MANTLE_HIP_H
+#define MANTLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_OK 0
+#define MC_EINVAL (-1)
+#define MC_EUNSUPPORTED (-2)
+#define MC_EWORKSPACE (-3)
+
+enum { MC_F32 = 0, MC_BF16 = 1 };
+enum { MC_PAD_ZEROS = 0, MC_PAD_REPLICATE = 1, MC_PAD_REFLECT = 2 };
+enum { MC_ACT_NONE = 0, MC_ACT_GELU = 1, MC_ACT_RELU = 2, MC_ACT_SILU = 3, MC_ACT_TANH = 4,
+       MC_ACT_SELU = 5, MC_ACT_ELU = 6 };
+/* what follows the convolution inside one reference layer */
+enum { MC_POST_NONE = 0,   /* plain nn.Conv2d (Unet conv[-1], ConvAE final conv)          */
+       MC_POST_ACT = 1,    /* conv -> act (Unet conv[-2])                                  */
+       MC_POST_GN_ACT = 2  /* conv -> GroupNorm -> act (FluidLayer; Unet conv[-3] + gn[0]) */ };
+/* where the gradient w.r.t. an activated tensor comes from (backward) */
+enum { MC_GSRC_NONE = 0,
+       MC_GSRC_PLAIN = 1,      /* CB8 tensor of the same H x W                                         */
+       MC_GSRC_PADFOLD = 2,    /* dgrad output on the padded domain (H+2p)x(W+2p); the padding          */
+                               /* adjoint (reflect / replicate fold) is applied on read                */
+       MC_GSRC_PADFOLD_POOL = 3 /* same, through the adjoint of AvgPool(f): value/f^2 at (y/f, x/f)   */ };
+
+typedef struct {
+  int32_t n;          /* batch                                                       */
+  int32_t h, w;       /* INPUT spatial size                                          */
+  int32_t c_in0;      /* channels of source 0                                        */
+  int32_t c_in1;      /* channels of source 1 (torch.cat on dim 1) or 0              */
+  int32_t c_out;
+  int32_t k;          /* square kernel, 3 or 5                                       */
+  int32_t pad;        /* per side; output is (h + 2 pad - k + 1) x (w + 2 pad - k + 1) */
+  int32_t pad_mode;   /* MC_PAD_*                                                    */
+  int32_t dtype;      /* MC_F32 | MC_BF16 : element type of x0, x1, y                */
+  int32_t sym_h;      /* number of x-mirrored filters (SymmetricConv2d symmetry['h']), 0 = plain Conv2d */
+  int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
+} mc_conv_desc;
+
+typedef struct {
+  const void* ptr;    /* CB8 tensor, element type = desc dtype                        */
+  int32_t kind;       /* MC_GSRC_*                                                    */
+  int32_t pad;        /* p of the conv that produced the padded-domain gradient       */
+  int32_t pad_mode;   /* MC_PAD_* of that conv                                        */
+  int32_t pool;       /* f for MC_GSRC_PADFOLD_POOL                                   */
+  int32_t hs, ws;     /* unpadded spatial size of the tensor `ptr` is the gradient of */
+} mc_grad_src;
+
+int mc_version(void);
+const char* mc_strerror(int code);
+
+/* ---- boundary layout conversion ---------------------------------------------------------- */
+/* NCHW f32 -> CB8 with optional W padding (Unet.forward's F.pad(inputs,(3,3,0,0),mode=r_p),
+ * pytorch_networks_convae.py:1991).  out is [n][ceil(c/8)][h][w + 2 pad_w][8]. */
+int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t pad_w,
+                 int32_t pad_mode, int32_t dtype, void* out, void* stream);
+/* CB8 -> NCHW f32, optionally subtracting a per-(n,c) mean and cropping crop_w columns on
+ * both sides ((y - mean(y))[..., 3:-3], pytorch_networks_convae.py:2024).  mean may be NULL. */
+int mc_unpack_nchw(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w,
+                   const float* mean_nc, int32_t dtype, float* out, void* stream);
+/* adjoint of mc_unpack_nchw: g NCHW f32 [n][c][h][w - 2 crop_w] -> CB8 [n][c8][h][w][8],
+ * zero in the cropped columns, minus mean_nc (the adjoint of the mean subtraction) if given. */
+int mc_pack_grad_nchw(const float* g, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w,
+                      const float* mean_nc, int32_t dtype, void* out, void* stream);
+/* per-(n,c) sums of an NCHW f32 tensor, scaled: out[n*c] = scale * sum_hw x. */
+int mc_sum_hw(const float* x, int32_t nc, int32_t hw, float scale, float* out, void* stream);
+
+/* ---- convolution (SymmetricConv2d.forward symmetric_layers_torch.py:113-138 +
+ *      nn.Conv2d._conv_forward: F.pad(mode) + F.conv2d; FluidLayer :764-786, Unet heads :1933-1979) */
+/* Bytes of the packed filter bank mc_pack_weights writes for this descriptor / direction. */
+size_t mc_packed_weight_bytes(const mc_conv_desc* d, int32_t dgrad);
+/* Expand the unique mirrored-filter bank (never materialised in the reference layout: the
+ * x-flipped copies are generated while packing) into the kernel-side bank.  dgrad != 0 packs
+ * the transposed, 180-degree-rotated bank used by mc_conv2d for the input gradient. */
+int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad, void* packed,
+                    void* stream);
+/* Number of spatial tiles per image the conv kernel uses for this descriptor (sizes stat partials). */
+int32_t mc_conv_tiles(const mc_conv_desc* d);
+/* y = conv(pad(cat(x0,x1))) + bias.  y0 (and y1 when c_out_split) are CB8 outputs.
+ * stat_partials (nullable): [n][tiles][c_out8*8][2] f32 per-tile (sum, sum of squares) of y,
+ * taken from the f32 accumulators — the first half of GroupNorm (FluidLayer :788). */
+int mc_conv2d(const mc_conv_desc* d, const void* x0, const void* x1, const void* packed_w,
+              const float* bias, void* y0, void* y1, float* stat_partials, void* stream);
+/* Filter/bias gradient.  partials: workspace of mc_wgrad_partial_bytes(d); the second call
+ * reduces it deterministically, folds mirrored filters back onto the unique bank
+ * (dW_unique[i] += flip_x(dW_full[U+i])) and ACCUMULATES into dw_unique / dbias. */
+size_t mc_wgrad_partial_bytes(const mc_conv_desc* d);
+int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const void* dy,
+                    void* partials, void* stream);
+int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float* dw_unique,
+                             float* dbias, void* stream);
+
+/* ---- GroupNorm + activation (FluidLayer :788-799; Unet :2016-2021) ------------------------ */
+/* (mean, rstd) per (n, group) from conv stat partials; eps 1e-5, biased variance.  Also emits
+ * per-(n,c) means of y when chan_mean != NULL (Unet's spatial zero-mean, :2024). */
+int mc_gn_finalize(const float* stat_partials, int32_t n, int32_t tiles, int32_t c, int32_t groups,
+                   int32_t hw, float eps, float* stats_ng2, float* chan_mean, void* stream);
+/* a = act(GN(y));  post = MC_POST_*.  pool > 1 additionally writes AvgPool2d(pool)(a) into
+ * pooled (Unet :2002, ConvAE :1051).  y, a, pooled are CB8 of `dtype`. */
+int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                  const float* stats_ng2, const float* gamma, const float* beta, int32_t post,
+                  int32_t act, int32_t pool, int32_t dtype, void* a, void* pooled, void* stream);
+/* Backward of act(GN(y)) given the gradient sources of a.  Phase 1 reduces
+ * (sum dz, sum dz*yhat) per (n,c) into partials [n][blocks][c8*8][2]; phase 2 (finalize)
+ * turns them into per-(n,g) means and accumulates dgamma/dbeta; phase 3 writes dy. */
+int32_t mc_gn_bwd_blocks(int32_t h, int32_t w);
+int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                         const float* stats_ng2, const float* gamma, const float* beta, int32_t post,
+                         int32_t act, int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1,
+                         float* partials, void* stream);
+int mc_gn_act_bwd_finalize(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups,
+                           int32_t hw, const float* gamma, float* m12_ng2, float* dgamma, float* dbeta,
+                           void* stream);
+int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                        const float* stats_ng2, const float* m12_ng2, const float* gamma,
+                        const float* beta, int32_t post, int32_t act, int32_t dtype,
+                        const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream);
+
+/* ---- resampling (nn.AvgPool2d, nn.Upsample(mode='bicubic'); Unet :2002,2009,2014; ConvAE :1051,1079) */
+int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t f, int32_t dtype,
+                   void* out, void* stream);
+/* taps: idx [out][4] int32 (clamped), wgt [out][4] f32, per axis (host-built in f64, A = -0.75). */
+int mc_bicubic_fwd(const void* x, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                   const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x, const float* wgt_x,
+                   int32_t dtype, void* out, void* stream);
+/* adjoint: transposed tap tables in CSR form per axis (start [in+1], j [], w []). */
+int mc_bicubic_bwd(const mc_grad_src* g, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                   const int32_t* ty_start, const int32_t* ty_j, const float* ty_w,
+                   const int32_t* tx_start, const int32_t* tx_j, const float* tx_w,
+                   int32_t dtype, void* dx, void* stream);
+
+/* ---- curl head (Unet :2038-2070): a*a_bound -> u = da/dy, v = -da/dx, antisymmetric walls;
+ *      optional T = clip(t_in, t_lo, t_hi) (:2040).  Planes are [h][w] f32 with a batch stride. --- */
+int mc_curl_head_fwd(const float* a, const float* t_in, int32_t n, int32_t h, int32_t w, int64_t in_batch_stride,
+                     float a_bound, float t_lo, float t_hi, float* u, float* v, float* t_out, void* stream);
+/* ws: workspace of 2*n*(h-2)*(w-2) floats.  ga / gt_in: gradients w.r.t. a / t_in (same batch stride). */
+int mc_curl_head_bwd(const float* gu, const float* gv, const float* gt_out, const float* t_in, int32_t n, int32_t h,
+                     int32_t w, float a_bound, float t_lo, float t_hi, float* ga, float* gt_in,
+                     int64_t g_batch_stride, int64_t in_batch_stride, float* ws, void* stream);
+
+/* ---- loss (Trainer.loss_fn multigpu.py:122-134; get_loss :250-305) + build-defined momentum -- */
+#define MC_LOSS_SLOTS 16
+enum { MC_S_U_SCALED = 0, MC_S_U_PLAIN, MC_S_V_SCALED, MC_S_V_PLAIN, MC_S_P_PLAIN, MC_S_T_PLAIN,
+       MC_S_DU, MC_S_DV, MC_S_MASS, MC_S_MASS_X0, MC_S_MASS_X1, MC_S_MASS_Y0, MC_S_MASS_Y1,
+       MC_S_MOMX, MC_S_MOMY, MC_S_SPARE };
+typedef struct {
+  int32_t n, h, w;
+  int32_t p_pred;          /* uvp = (u,v,p,T) if p_pred else (u,v,T)                      */
+  int32_t loss_type;       /* 0 mae, 1 mass, 2 curl                                        */
+  int32_t loss_scale;      /* Trainer.loss_scale                                           */
+  int32_t loss_derivative; /* Trainer.loss_derivative                                      */
+  int32_t l2;              /* 0: L1 (reference); 1: squared error for the data terms       */
+  float lambda_mom;        /* weight of the momentum residual term (0 = off)               */
+  float inv_h;             /* 1/h of the momentum residual (126)                           */
+  float ra;                /* Rayleigh number in the buoyancy term (1)                     */
+  int32_t t_grad;          /* 1: T is a network output (gets a gradient)                   */
+} mc_loss_desc;
+/* per-sample min/max of truth u,v over (H,W): mm [n][2][2] */
+int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w, float* mm, void* stream);
+/* Fused forward + backward of the data / derivative / divergence terms.  u,v,p,T: predictions
+ * [n][h][w] f32 with the given batch strides (p may be NULL); sums: MC_LOSS_SLOTS doubles
+ * (zeroed by the caller); gu..gT: d(loss)/d(pred), same strides as the predictions
+ * (overwritten).  The momentum term is added by mc_momentum_* below. */
+int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
+                    int64_t pred_batch_stride, const float* uvp, const float* mm, double* sums,
+                    float* gu, float* gv, float* gp, float* gT, void* stream);
+/* Stokes momentum residual (build-defined).  yc [h][w], paras [n][3] =
+ * (RaQ, FKT, FKP), scaler [n].  sx, sy: workspaces [n][h][w] f32. */
+int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, const float* p,
+                         const float* T, int64_t pred_batch_stride, const float* yc, const float* paras,
+                         const float* scaler, double* sums, float* sx, float* sy, void* stream);
+int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pred_batch_stride, const float* yc,
+                        const float* paras, const float* scaler, const float* sx, const float* sy,
+                        float* gu, float* gv, float* gp, float* gT, void* stream);
+/* loss6 (+momentum) from the sums, exactly as get_loss combines them: out[8] f32 =
+ * (loss, loss_true_u, loss_true_v, loss_p, loss_T, mean mass, mom, 0). */
+int mc_loss_finalize(const mc_loss_desc* d, const double* sums, float* out8, void* stream);
+
+/* ---- optimizer (torch.optim.Adam, multigpu.py:761-763) --------------------------------------- */
+/* One fused multi-tensor step over flat f32 buffers; grad_scale folds the 1/world_size of the
+ * data-parallel average; lr is read from device memory so a captured graph can be replayed
+ * while MultiStepLR changes it. step_count (device int32) is incremented by the kernel. */
+int mc_adam_step_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                      const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      float grad_scale, int32_t* step_count_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANTLE_HIP_H */

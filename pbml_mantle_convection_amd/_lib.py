@@ -1,0 +1,139 @@
+"""ctypes binding of libmantle_hip.so (the C ABI declared in include/mantle_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a kernel call
+fails, a RuntimeError is raised.  PyTorch is plumbing only (device memory, streams)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmantle_hip.so")
+
+MC_F32, MC_BF16 = 0, 1
+PAD_MODES = {"zeros": 0, "constant": 0, "replicate": 1, "reflect": 2}
+ACTS = {"none": 0, "gelu": 1, "relu": 2, "silu": 3, "tanh": 4, "selu": 5, "elu": 6}
+POST_NONE, POST_ACT, POST_GN_ACT = 0, 1, 2
+GSRC_NONE, GSRC_PLAIN, GSRC_PADFOLD, GSRC_PADFOLD_POOL = 0, 1, 2, 3
+LOSS_SLOTS = 16
+LOSS_TYPES = {"mae": 0, "mass": 1, "curl": 2}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "c_in0", "c_in1", "c_out", "k", "pad", "pad_mode",
+                                          "dtype", "sym_h", "c_out_split")]
+
+
+class GradSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("kind", C.c_int32), ("pad", C.c_int32), ("pad_mode", C.c_int32),
+                ("pool", C.c_int32), ("hs", C.c_int32), ("ws", C.c_int32)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("p_pred", C.c_int32),
+                ("loss_type", C.c_int32), ("loss_scale", C.c_int32), ("loss_derivative", C.c_int32),
+                ("l2", C.c_int32), ("lambda_mom", C.c_float), ("inv_h", C.c_float), ("ra", C.c_float),
+                ("t_grad", C.c_int32)]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_CD, _GS, _LD = C.POINTER(ConvDesc), C.POINTER(GradSrc), C.POINTER(LossDesc)
+
+# name -> (restype, argtypes); must list EVERY symbol include/mantle_hip.h declares
+SIGNATURES = {
+    "mc_version": (C.c_int, []),
+    "mc_strerror": (C.c_char_p, [C.c_int]),
+    "mc_pack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_unpack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
+    "mc_packed_weight_bytes": (_sz, [_CD, _i32]),
+    "mc_pack_weights": (C.c_int, [_CD, _vp, _i32, _vp, _vp]),
+    "mc_conv_tiles": (_i32, [_CD]),
+    "mc_conv2d": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_wgrad_partial_bytes": (_sz, [_CD]),
+    "mc_conv2d_wgrad": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp]),
+    "mc_conv2d_wgrad_finalize": (C.c_int, [_CD, _vp, _vp, _vp, _vp]),
+    "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
+                                _vp, _vp]),
+    "mc_gn_bwd_blocks": (_i32, [_i32, _i32]),
+    "mc_gn_act_bwd_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _GS,
+                                       _GS, _vp, _vp]),
+    "mc_gn_act_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mc_gn_act_bwd_apply": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                      _GS, _GS, _vp, _vp]),
+    "mc_avgpool_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_bicubic_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "mc_bicubic_bwd": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                 _vp, _vp]),
+    "mc_curl_head_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "mc_curl_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _i64, _i64,
+                                   _vp, _vp]),
+    "mc_loss_minmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_loss_fwd_bwd": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_momentum_residual": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_momentum_adjoint": (C.c_int, [_LD, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_loss_finalize": (C.c_int, [_LD, _vp, _vp, _vp]),
+    "mc_adam_step_flat": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+}
+
+# entry points whose return value is a quantity, not a status code
+VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_packed_weight_bytes", "mc_conv_tiles",
+                   "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks"}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m pbml_mantle_convection_amd.build_ext` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = ABI/header drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MantleHipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mc_strerror(int(rc)).decode()
+        raise MantleHipError(f"libmantle_hip: {what} failed with code {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if name not in VALUE_RETURNING:
+        check(rc, name)
+    return rc
+
+
+def require_cuda(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must live on the MI355X (HIP device tensor): this framework's hot path is HIP-only and "
+            "has no CPU fallback")

@@ -1,0 +1,168 @@
+// Shared device helpers for libmantle_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mantle_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+#define MC_CHECK_LAUNCH()                                 \
+  do {                                                    \
+    hipError_t e__ = hipGetLastError();                   \
+    if (e__ != hipSuccess) return (int)e__;               \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 on gfx950: RNE, NaN-preserving
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+// ---- 8-channel vector access in the CB8 layout ------------------------------------------------
+template <typename T> struct V8;
+template <> struct V8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&o)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+};
+template <> struct V8<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[8]) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+    o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+    o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
+    o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[8]) {
+    uint4 a;
+    a.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    a.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    a.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+    a.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = a;
+  }
+};
+
+__device__ __forceinline__ size_t cb8_index(int n, int cb, int y, int x, int C8, int H, int W) {
+  return ((((size_t)n * C8 + cb) * H + y) * (size_t)W + x) * 8;
+}
+
+// ---- padding index maps (F.pad modes; reflect excludes the edge pixel) -------------------------
+// returns the source index for padded coordinate i (may be <0 or >=n), or -1 for "zero".
+__device__ __forceinline__ int pad_map(int i, int n, int mode) {
+  if (i >= 0 && i < n) return i;
+  if (mode == MC_PAD_ZEROS) return -1;
+  if (mode == MC_PAD_REPLICATE) return i < 0 ? 0 : n - 1;
+  // reflect
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return (i >= 0 && i < n) ? i : -1;
+}
+
+// ---- activations and derivatives (nn.GELU() exact erf form etc.) -------------------------------
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  switch (act) {
+    case MC_ACT_GELU: return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+    case MC_ACT_RELU: return z > 0.f ? z : 0.f;
+    case MC_ACT_SILU: return z / (1.0f + expf(-z));
+    case MC_ACT_TANH: return tanhf(z);
+    case MC_ACT_SELU: {
+      const float al = 1.6732632423543772848170429916717f, sc = 1.0507009873554804934193349852946f;
+      return sc * (z > 0.f ? z : al * (expf(z) - 1.0f));
+    }
+    case MC_ACT_ELU: return z > 0.f ? z : (expf(z) - 1.0f);
+    default: return z;
+  }
+}
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  switch (act) {
+    case MC_ACT_GELU: {
+      float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+      return cdf + z * pdf;
+    }
+    case MC_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case MC_ACT_SILU: {
+      float s = 1.0f / (1.0f + expf(-z));
+      return s * (1.0f + z * (1.0f - s));
+    }
+    case MC_ACT_TANH: {
+      float t = tanhf(z);
+      return 1.0f - t * t;
+    }
+    case MC_ACT_SELU: {
+      const float al = 1.6732632423543772848170429916717f, sc = 1.0507009873554804934193349852946f;
+      return z > 0.f ? sc : sc * al * expf(z);
+    }
+    case MC_ACT_ELU: return z > 0.f ? 1.f : expf(z);
+    default: return 1.f;
+  }
+}
+
+// ---- wave / block reductions (wave = 64) --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- gradient sources of an activated tensor (see mc_grad_src) ---------------------------------
+// candidates of padded coordinates that fold onto interior coordinate i: writes up to 3 padded
+// indices (already offset by +p, i.e. indices into the padded buffer) and returns the count.
+__device__ __forceinline__ int fold_candidates(int i, int n, int p, int mode, int (&out)[6]) {
+  int cnt = 0;
+  out[cnt++] = i + p;
+  if (mode == MC_PAD_REFLECT) {
+    if (i >= 1 && i <= p) out[cnt++] = p - i;                       // padded coord -i
+    int j = 2 * (n - 1) - i;                                        // mirror about the last pixel
+    if (j >= n && j < n + p) out[cnt++] = j + p;
+  } else if (mode == MC_PAD_REPLICATE) {
+    if (i == 0) for (int q = 0; q < p && cnt < 6; ++q) out[cnt++] = q;
+    if (i == n - 1) for (int q = 0; q < p && cnt < 6; ++q) out[cnt++] = n + p + q;
+  }
+  return cnt;
+}
+
+template <typename T>
+__device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int cb, int y, int x, int C8,
+                                               float (&acc)[8]) {
+  if (g.kind == MC_GSRC_NONE || g.ptr == nullptr) return;
+  const T* base = reinterpret_cast<const T*>(g.ptr);
+  float v[8];
+  if (g.kind == MC_GSRC_PLAIN) {
+    V8<T>::ld(base + cb8_index(n, cb, y, x, C8, g.hs, g.ws), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    return;
+  }
+  float scale = 1.0f;
+  int yy = y, xx = x;
+  if (g.kind == MC_GSRC_PADFOLD_POOL) {
+    yy = y / g.pool; xx = x / g.pool;
+    if (yy >= g.hs || xx >= g.ws) return;   // floor mode: trailing rows/cols are not pooled
+    scale = 1.0f / (float)(g.pool * g.pool);
+  }
+  const int Hp = g.hs + 2 * g.pad, Wp = g.ws + 2 * g.pad;
+  int cy[6], cx[6];
+  int ny = fold_candidates(yy, g.hs, g.pad, g.pad_mode, cy);
+  int nx = fold_candidates(xx, g.ws, g.pad, g.pad_mode, cx);
+  for (int a = 0; a < ny; ++a)
+    for (int b = 0; b < nx; ++b) {
+      V8<T>::ld(base + cb8_index(n, cb, cy[a], cx[b], C8, Hp, Wp), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += scale * v[j];
+    }
+}

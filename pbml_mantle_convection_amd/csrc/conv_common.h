@@ -1,0 +1,55 @@
+// Geometry shared by the f32 and bf16 convolution paths.
+#pragma once
+#include "common.h"
+
+struct ConvGeom {
+  int N, H, W, Ho, Wo, K, pad, pad_mode;
+  int Cin0, Cin1, Cin;      // real channels
+  int CB0, CB1, CBin, CinP; // 8-channel blocks of source 0 / 1 / both; padded channel count
+  int Cout, CBout, CoutP;
+  int split8;               // dgrad: first split8 output blocks go to y0 (0 = no split)
+  int tiles_x, tiles_y, tiles;
+  int wgrad_G;              // number of partial slabs of the filter-gradient reduction
+  int sym_h, U;             // mirrored filters / unique filters
+  int dtype;
+};
+
+// fills g from d; returns MC_OK or an error code.  tile_h/tile_w = output tile of the kernel family.
+static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvGeom& g) {
+  if (!d) return MC_EINVAL;
+  if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c_in0 <= 0 || d->c_in1 < 0 || d->c_out <= 0) return MC_EINVAL;
+  if (d->k != 3 && d->k != 5) return MC_EUNSUPPORTED;
+  if (d->pad < 0 || d->pad > d->k - 1) return MC_EINVAL;
+  if (d->pad_mode < MC_PAD_ZEROS || d->pad_mode > MC_PAD_REFLECT) return MC_EINVAL;
+  if (d->pad_mode == MC_PAD_REFLECT && (d->pad >= d->h || d->pad >= d->w)) return MC_EINVAL;
+  if (d->c_in1 > 0 && (d->c_in0 % 8) != 0) return MC_EUNSUPPORTED;
+  if (d->sym_h < 0 || (d->sym_h & 1) || d->sym_h > d->c_out) return MC_EINVAL;
+  if (d->c_out_split != 0 && (d->c_out_split < 0 || d->c_out_split >= d->c_out || (d->c_out_split % 8) != 0))
+    return MC_EINVAL;
+  g.N = d->n; g.H = d->h; g.W = d->w; g.K = d->k; g.pad = d->pad; g.pad_mode = d->pad_mode;
+  g.Ho = d->h + 2 * d->pad - d->k + 1;
+  g.Wo = d->w + 2 * d->pad - d->k + 1;
+  if (g.Ho <= 0 || g.Wo <= 0) return MC_EINVAL;
+  g.Cin0 = d->c_in0; g.Cin1 = d->c_in1; g.Cin = d->c_in0 + d->c_in1;
+  g.CB0 = (d->c_in0 + 7) / 8; g.CB1 = (d->c_in1 + 7) / 8; g.CBin = g.CB0 + g.CB1; g.CinP = g.CBin * 8;
+  g.Cout = d->c_out; g.CBout = (d->c_out + 7) / 8; g.CoutP = g.CBout * 8;
+  g.split8 = d->c_out_split / 8;
+  g.tiles_x = (g.Wo + tile_w - 1) / tile_w;
+  g.tiles_y = (g.Ho + tile_h - 1) / tile_h;
+  g.tiles = g.tiles_x * g.tiles_y;
+  g.sym_h = d->sym_h; g.U = d->c_out - d->sym_h / 2;
+  g.dtype = d->dtype;
+  long slab = (long)g.CoutP * ((long)g.CinP * g.K * g.K + 1) * 4;
+  long G = (64L << 20) / slab;
+  if (G < 32) G = 32;
+  if (G > 1024) G = 1024;
+  long work = (long)g.N * g.tiles;
+  if (G > work) G = work;
+  g.wgrad_G = (int)G;
+  return MC_OK;
+}
+
+// padded input-channel index of global input channel ci (concat: source 0 then source 1)
+static __host__ __device__ inline int cin_padded_index(int ci, int Cin0, int CB0) {
+  return ci < Cin0 ? ci : CB0 * 8 + (ci - Cin0);
+}

@@ -1,0 +1,743 @@
+// Layout conversion, GroupNorm(+activation) forward/backward, pooling, bicubic resampling,
+// curl head.  All HBM-bound streaming kernels over the CB8 layout: one thread moves one
+// 8-channel vector (32 B f32 / 16 B bf16), consecutive lanes take consecutive pixels.
+#include "common.h"
+
+namespace {
+
+// =================================================================================================
+// NCHW f32 <-> CB8
+// =================================================================================================
+template <typename T>
+__global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int H, int W, int pad_w, int mode,
+                            T* __restrict__ out) {
+  const int Wp = W + 2 * pad_w, C8 = (C + 7) / 8;
+  size_t total = (size_t)N * C8 * H * Wp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int xo = (int)(i % Wp);
+    size_t r = i / Wp;
+    int y = (int)(r % H); r /= H;
+    int cb = (int)(r % C8);
+    int n = (int)(r / C8);
+    int xs = pad_map(xo - pad_w, W, mode);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = cb * 8 + j;
+      v[j] = (c < C && xs >= 0) ? x[(((size_t)n * C + c) * H + y) * W + xs] : 0.f;
+    }
+    V8<T>::st(out + i * 8, v);
+  }
+}
+
+template <typename T>
+__global__ void k_unpack_nchw(const T* __restrict__ x, int N, int C, int H, int W, int crop,
+                              const float* __restrict__ mean_nc, float* __restrict__ out) {
+  const int Wo = W - 2 * crop, C8 = (C + 7) / 8;
+  size_t total = (size_t)N * C8 * H * Wo;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int xo = (int)(i % Wo);
+    size_t r = i / Wo;
+    int y = (int)(r % H); r /= H;
+    int cb = (int)(r % C8);
+    int n = (int)(r / C8);
+    float v[8];
+    V8<T>::ld(x + cb8_index(n, cb, y, xo + crop, C8, H, W), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = cb * 8 + j;
+      if (c < C) {
+        float m = mean_nc ? mean_nc[n * C + c] : 0.f;
+        out[(((size_t)n * C + c) * H + y) * Wo + xo] = v[j] - m;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void k_pack_grad_nchw(const float* __restrict__ g, int N, int C, int H, int W, int crop,
+                                 const float* __restrict__ mean_nc, T* __restrict__ out) {
+  const int Wi = W - 2 * crop, C8 = (C + 7) / 8;
+  size_t total = (size_t)N * C8 * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int xo = (int)(i % W);
+    size_t r = i / W;
+    int y = (int)(r % H); r /= H;
+    int cb = (int)(r % C8);
+    int n = (int)(r / C8);
+    int xi = xo - crop;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = cb * 8 + j;
+      float val = 0.f;
+      if (c < C) {
+        if (xi >= 0 && xi < Wi) val = g[(((size_t)n * C + c) * H + y) * Wi + xi];
+        if (mean_nc) val -= mean_nc[n * C + c];
+      }
+      v[j] = val;
+    }
+    V8<T>::st(out + i * 8, v);
+  }
+}
+
+__global__ void k_sum_hw(const float* __restrict__ x, int hw, float scale, float* __restrict__ out) {
+  const float* p = x + (size_t)blockIdx.x * hw;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) s += (double)p[i];
+  s = wave_sum_d(s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)scale);
+}
+
+// =================================================================================================
+// GroupNorm statistics from the conv epilogue's per-tile (sum, sumsq) partials
+// =================================================================================================
+// one block per (n, g); also optional per-(n,c) means (block g handles its own channels)
+__global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, int CP, int groups, int hw,
+                              float eps, float* __restrict__ stats, float* __restrict__ chan_mean) {
+  const int n = blockIdx.y, g = blockIdx.x;
+  const int cpg = C / groups;
+  double s = 0.0, ss = 0.0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    double cs = 0.0, css = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+      const float* p = part + (((size_t)n * tiles + t) * CP + c) * 2;
+      cs += (double)p[0];
+      css += (double)p[1];
+    }
+    cs = wave_sum_d(cs);
+    css = wave_sum_d(css);
+    if (chan_mean && threadIdx.x == 0) chan_mean[n * C + c] = (float)(cs / (double)hw);
+    s += cs;
+    ss += css;
+  }
+  if (threadIdx.x == 0 && stats) {
+    double m = (double)cpg * (double)hw;
+    double mean = s / m;
+    double var = ss / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((size_t)n * groups + g) * 2 + 0] = (float)mean;
+    stats[((size_t)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// =================================================================================================
+// a = act(GN(y)) [+ AvgPool(POOL)(a)]
+// =================================================================================================
+struct GnArgs {
+  int N, C, C8, H, W, groups, cpg, post, act;
+  const float* stats;
+  const float* gamma;
+  const float* beta;
+};
+
+__device__ __forceinline__ void gn_coef(const GnArgs& a, int n, int cb, float (&sc)[8], float (&sh)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int c = cb * 8 + j;
+    if (a.post == MC_POST_GN_ACT && c < a.C) {
+      int g = c / a.cpg;
+      float mean = a.stats[((size_t)n * a.groups + g) * 2], rstd = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+      float ga = a.gamma[c], be = a.beta[c];
+      sc[j] = rstd * ga;
+      sh[j] = be - mean * rstd * ga;
+    } else {
+      sc[j] = (c < a.C) ? 1.f : 0.f;
+      sh[j] = 0.f;
+    }
+  }
+}
+
+template <typename T, int POOL>
+__global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ out, T* __restrict__ pooled) {
+  // one thread per POOLxPOOL pixel block of one channel block
+  const int Hb = (a.H + POOL - 1) / POOL, Wb = (a.W + POOL - 1) / POOL;
+  const int Hp = a.H / POOL, Wp = a.W / POOL;
+  const int n = blockIdx.z, cb = blockIdx.y;
+  float sc[8], sh[8];
+  gn_coef(a, n, cb, sc, sh);
+  const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hb * Wb; i += gridDim.x * blockDim.x) {
+    int by = i / Wb, bx = i % Wb;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < POOL; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < POOL; ++dx) {
+        int yy = by * POOL + dy, xx = bx * POOL + dx;
+        if (yy < a.H && xx < a.W) {
+          float v[8];
+          size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
+          V8<T>::ld(y + idx, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+            acc[j] += v[j];
+          }
+          V8<T>::st(out + idx, v);
+        }
+      }
+    if (POOL > 1 && by < Hp && bx < Wp) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= 1.0f / (POOL * POOL);
+      V8<T>::st(pooled + cb8_index(n, cb, by, bx, a.C8, Hp, Wp), acc);
+    }
+  }
+}
+
+template <typename T>
+__global__ void k_avgpool(const T* __restrict__ x, int C8, int H, int W, int f, T* __restrict__ out) {
+  const int Hp = H / f, Wp = W / f;
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hp * Wp; i += gridDim.x * blockDim.x) {
+    int by = i / Wp, bx = i % Wp;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) {
+        float v[8];
+        V8<T>::ld(x + cb8_index(n, cb, by * f + dy, bx * f + dx, C8, H, W), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= 1.0f / (float)(f * f);
+    V8<T>::st(out + cb8_index(n, cb, by, bx, C8, Hp, Wp), acc);
+  }
+}
+
+// =================================================================================================
+// backward of act(GN(y))
+// =================================================================================================
+// phase 1: partial[n][blk][c][2] = (sum dz, sum dz * yhat) over this block's pixels
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
+                                                       mc_grad_src g1, float* __restrict__ part, int CP) {
+  const int n = blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  float sc[8], sh[8], mean[8], rstd[8];
+  gn_coef(a, n, cb, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int c = cb * 8 + j;
+    if (c < a.C) {
+      int g = c / a.cpg;
+      mean[j] = a.stats[((size_t)n * a.groups + g) * 2];
+      rstd[j] = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+    } else { mean[j] = 0.f; rstd[j] = 0.f; }
+  }
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int HW = a.H * a.W;
+  for (int i = blk * blockDim.x + threadIdx.x; i < HW; i += nblk * blockDim.x) {
+    int yy = i / a.W, xx = i % a.W;
+    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
+    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dz = da[j] * act_bwd(v[j] * sc[j] + sh[j], a.act);
+      s1[j] += dz;
+      s2[j] += dz * (v[j] - mean[j]) * rstd[j];
+    }
+  }
+  __shared__ float red[4][16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][j * 2] = r1; red[threadIdx.x >> 6][j * 2 + 1] = r2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    int c = cb * 8 + (threadIdx.x >> 1);
+    part[(((size_t)n * nblk + blk) * CP + c) * 2 + (threadIdx.x & 1)] = r;
+  }
+}
+
+// phase 2: one block per group g (all n): m12[n][g] = (sum_c gamma_c s1, sum_c gamma_c s2)/M;
+// dgamma[c] += sum_n s2[n][c]; dbeta[c] += sum_n s1[n][c]
+__global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blocks, int C, int CP, int groups,
+                                  int hw, const float* __restrict__ gamma, float* __restrict__ m12,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int g = blockIdx.x, cpg = C / groups;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    double tg = 0.0, tb = 0.0;
+    for (int n = 0; n < N; ++n) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
+        const float* p = part + (((size_t)n * blocks + t) * CP + c) * 2;
+        a1 += (double)p[0];
+        a2 += (double)p[1];
+      }
+      a1 = wave_sum_d(a1);
+      a2 = wave_sum_d(a2);
+      tb += a1;
+      tg += a2;
+      if (threadIdx.x == 0 && m12) {
+        double M = (double)cpg * (double)hw;
+        float* o = m12 + ((size_t)n * groups + g) * 2;
+        float ga = gamma ? gamma[c] : 1.f;
+        if (c == g * cpg) { o[0] = 0.f; o[1] = 0.f; }
+        o[0] += (float)(ga * a1 / M);
+        o[1] += (float)(ga * a2 / M);
+      }
+    }
+    if (threadIdx.x == 0) {
+      if (dgamma) dgamma[c] += (float)tg;
+      if (dbeta) dbeta[c] += (float)tb;
+    }
+  }
+}
+
+// phase 3: dy = rstd (dz gamma - m1 - yhat m2)   (GN)   |   dy = da act'(y)   (act only)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restrict__ y, const float* __restrict__ m12,
+                                                      mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  float sc[8], sh[8], mean[8], rstd[8], ga[8], m1[8], m2[8];
+  gn_coef(a, n, cb, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int c = cb * 8 + j;
+    mean[j] = 0.f; rstd[j] = 0.f; ga[j] = 0.f; m1[j] = 0.f; m2[j] = 0.f;
+    if (c < a.C) {
+      if (a.post == MC_POST_GN_ACT) {
+        int g = c / a.cpg;
+        mean[j] = a.stats[((size_t)n * a.groups + g) * 2];
+        rstd[j] = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+        ga[j] = a.gamma[c];
+        m1[j] = m12[((size_t)n * a.groups + g) * 2];
+        m2[j] = m12[((size_t)n * a.groups + g) * 2 + 1];
+      } else { ga[j] = 1.f; rstd[j] = 1.f; }
+    }
+  }
+  const int HW = a.H * a.W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    int yy = i / a.W, xx = i % a.W;
+    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+    size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
+    V8<T>::ld(y + idx, v);
+    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dz = da[j] * act_bwd(v[j] * sc[j] + sh[j], a.act);
+      if (a.post == MC_POST_GN_ACT) {
+        float yh = (v[j] - mean[j]) * rstd[j];
+        o[j] = rstd[j] * (dz * ga[j] - m1[j] - yh * m2[j]);
+      } else {
+        o[j] = dz * ga[j];
+      }
+    }
+    V8<T>::st(dy + idx, o);
+  }
+}
+
+// =================================================================================================
+// bicubic resampling with host-built tap tables
+// =================================================================================================
+template <typename T>
+__global__ void k_bicubic_fwd(const T* __restrict__ x, int C8, int Hi, int Wi, int Ho, int Wo,
+                              const int* __restrict__ iy, const float* __restrict__ wy,
+                              const int* __restrict__ ix, const float* __restrict__ wx, T* __restrict__ out) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Ho * Wo; i += gridDim.x * blockDim.x) {
+    int yo = i / Wo, xo = i % Wo;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int ys = iy[yo * 4 + a];
+      float wa = wy[yo * 4 + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float v[8];
+        V8<T>::ld(x + cb8_index(n, cb, ys, ix[xo * 4 + b], C8, Hi, Wi), v);
+        float w = wa * wx[xo * 4 + b];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+      }
+    }
+    V8<T>::st(out + cb8_index(n, cb, yo, xo, C8, Ho, Wo), acc);
+  }
+}
+
+template <typename T>
+__global__ void k_bicubic_bwd(mc_grad_src g, int C8, int Hi, int Wi, const int* __restrict__ tys,
+                              const int* __restrict__ tyj, const float* __restrict__ tyw,
+                              const int* __restrict__ txs, const int* __restrict__ txj,
+                              const float* __restrict__ txw, T* __restrict__ dx) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wi; i += gridDim.x * blockDim.x) {
+    int yi = i / Wi, xi = i % Wi;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = tys[yi]; a < tys[yi + 1]; ++a) {
+      int yo = tyj[a];
+      float wa = tyw[a];
+      for (int b = txs[xi]; b < txs[xi + 1]; ++b) {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
+        float w = wa * txw[b];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+      }
+    }
+    V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
+  }
+}
+
+// =================================================================================================
+// curl head (Unet :2038-2068)
+// =================================================================================================
+// raw stencil values (before wall/corner fix-up) at interior-clamped positions
+__device__ __forceinline__ float curl_u_raw(const float* a, int y, int x, int H, int W) {
+  // u_in[y'][x'] = 0.5 (a[y'+2][x'+1] - a[y'][x'+1]), y' in [0,H-3], x' in [0,W-3]; replicate pad by 1
+  int yc = min(max(y - 1, 0), H - 3), xc = min(max(x - 1, 0), W - 3);
+  return 0.5f * (a[(size_t)(yc + 2) * W + xc + 1] - a[(size_t)yc * W + xc + 1]);
+}
+__device__ __forceinline__ float curl_v_raw(const float* a, int y, int x, int H, int W) {
+  int yc = min(max(y - 1, 0), H - 3), xc = min(max(x - 1, 0), W - 3);
+  return -0.5f * (a[(size_t)(yc + 1) * W + xc + 2] - a[(size_t)(yc + 1) * W + xc]);
+}
+
+__global__ void k_curl_fwd(const float* __restrict__ a_, int H, int W, int64_t abs_, float ab, float* __restrict__ u,
+                           float* __restrict__ v) {
+  const int n = blockIdx.y;
+  const float* a = a_ + (size_t)n * abs_;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+    int y = i / W, x = i % W;
+    bool corner = (y == 0 || y == H - 1) && (x == 0 || x == W - 1);
+    float uu, vv;
+    if (x == 0) uu = -curl_u_raw(a, y, 1, H, W);
+    else if (x == W - 1) uu = -curl_u_raw(a, y, W - 2, H, W);
+    else uu = curl_u_raw(a, y, x, H, W);
+    if (y == 0) vv = -curl_v_raw(a, 1, x, H, W);
+    else if (y == H - 1) vv = -curl_v_raw(a, H - 2, x, H, W);
+    else vv = curl_v_raw(a, y, x, H, W);
+    u[(size_t)n * H * W + i] = corner ? 0.f : ab * uu;
+    v[(size_t)n * H * W + i] = corner ? 0.f : ab * vv;
+  }
+}
+
+// adjoint: fold the wall / replicate structure of (gu, gv) onto the interior stencil outputs,
+// then apply the transposed stencils.
+__global__ void k_curl_bwd_fold(const float* __restrict__ gu, const float* __restrict__ gv, int H, int W,
+                                float* __restrict__ eu, float* __restrict__ ev) {
+  // eu/ev: [n][H-2][W-2] effective gradients w.r.t. the stencil outputs u_in, v_in
+  const int n = blockIdx.y;
+  const float* gun = gu + (size_t)n * H * W;
+  const float* gvn = gv + (size_t)n * H * W;
+  const int Hi = H - 2, Wi = W - 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wi; i += gridDim.x * blockDim.x) {
+    int yp = i / Wi, xp = i % Wi;
+    // u: rows y with clamp(y-1)==yp : y = yp+1, plus y=0 if yp==0, y=H-1 if yp==H-3
+    float su = 0.f, sv = 0.f;
+    int ys[3], ny = 0;
+    ys[ny++] = yp + 1;
+    if (yp == 0) ys[ny++] = 0;
+    if (yp == Hi - 1) ys[ny++] = H - 1;
+    int xs[3], nx = 0;
+    xs[nx++] = xp + 1;
+    if (xp == 0) xs[nx++] = 0;
+    if (xp == Wi - 1) xs[nx++] = W - 1;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        int y = ys[a], x = xs[b];
+        bool corner = (y == 0 || y == H - 1) && (x == 0 || x == W - 1);
+        if (corner) continue;
+        // u: wall columns x==0 / W-1 take -u[:, 1] / -u[:, W-2], which are u_in[.., 0] / u_in[.., W-3]
+        su += ((x == 0 || x == W - 1) ? -1.f : 1.f) * gun[(size_t)y * W + x];
+        sv += ((y == 0 || y == H - 1) ? -1.f : 1.f) * gvn[(size_t)y * W + x];
+      }
+    eu[(size_t)n * Hi * Wi + i] = su;
+    ev[(size_t)n * Hi * Wi + i] = sv;
+  }
+}
+
+__global__ void k_curl_bwd_stencil(const float* __restrict__ eu, const float* __restrict__ ev, int H, int W, float ab,
+                                   float* __restrict__ ga_, int64_t gabs) {
+  const int n = blockIdx.y;
+  const int Hi = H - 2, Wi = W - 2;
+  const float* eun = eu + (size_t)n * Hi * Wi;
+  const float* evn = ev + (size_t)n * Hi * Wi;
+  float* ga = ga_ + (size_t)n * gabs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+    int y = i / W, x = i % W;
+    float acc = 0.f;
+    // u_in[yp][xp] = 0.5 (a[yp+2][xp+1] - a[yp][xp+1])
+    int xp = x - 1;
+    if (xp >= 0 && xp < Wi) {
+      if (y - 2 >= 0 && y - 2 < Hi) acc += 0.5f * eun[(size_t)(y - 2) * Wi + xp];
+      if (y < Hi) acc -= 0.5f * eun[(size_t)y * Wi + xp];
+    }
+    // v_in[yp][xp] = -0.5 (a[yp+1][xp+2] - a[yp+1][xp])
+    int yp = y - 1;
+    if (yp >= 0 && yp < Hi) {
+      if (x - 2 >= 0 && x - 2 < Wi) acc -= 0.5f * evn[(size_t)yp * Wi + x - 2];
+      if (x < Wi) acc += 0.5f * evn[(size_t)yp * Wi + x];
+    }
+    ga[i] = ab * acc;
+  }
+}
+
+__global__ void k_clip_fwd(const float* __restrict__ t, int hw, int64_t bs, float lo, float hi, float* __restrict__ o) {
+  const int n = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x)
+    o[(size_t)n * hw + i] = fminf(fmaxf(t[(size_t)n * bs + i], lo), hi);
+}
+// torch.clip passes the gradient where lo <= x <= hi
+__global__ void k_clip_bwd(const float* __restrict__ go, const float* __restrict__ t, int hw, int64_t bs, int64_t gbs, float lo,
+                           float hi, float* __restrict__ gi) {
+  const int n = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+    float x = t[(size_t)n * bs + i];
+    gi[(size_t)n * gbs + i] = (x >= lo && x <= hi) ? go[(size_t)n * hw + i] : 0.f;
+  }
+}
+
+inline dim3 grid1(size_t total, int block = 256, int cap = 8192) {
+  size_t g = (total + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+inline dim3 grid3(int per_plane, int c8, int n, int block = 256, int capx = 64) {
+  int gx = (per_plane + block - 1) / block;
+  if (gx > capx) gx = capx;
+  if (gx < 1) gx = 1;
+  return dim3(gx, c8, n);
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+extern "C" {
+
+int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t pad_w, int32_t pad_mode,
+                 int32_t dtype, void* out, void* stream) {
+  if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || pad_w < 0) return MC_EINVAL;
+  if (pad_mode == MC_PAD_REFLECT && pad_w >= w) return MC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  size_t total = (size_t)n * ((c + 7) / 8) * h * (w + 2 * pad_w);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_nchw<float>, grid1(total), dim3(256), 0, s, x, n, c, h, w, pad_w, pad_mode, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, x, n, c, h, w, pad_w, pad_mode, (bf16_t*)out);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_unpack_nchw(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w, const float* mean_nc,
+                   int32_t dtype, float* out, void* stream) {
+  if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 2 * crop_w || crop_w < 0) return MC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  size_t total = (size_t)n * ((c + 7) / 8) * h * (w - 2 * crop_w);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_unpack_nchw<float>, grid1(total), dim3(256), 0, s, (const float*)x, n, c, h, w, crop_w, mean_nc, out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_unpack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, (const bf16_t*)x, n, c, h, w, crop_w, mean_nc, out);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_pack_grad_nchw(const float* g, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w, const float* mean_nc,
+                      int32_t dtype, void* out, void* stream) {
+  if (!g || !out || n <= 0 || c <= 0 || h <= 0 || w <= 2 * crop_w || crop_w < 0) return MC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  size_t total = (size_t)n * ((c + 7) / 8) * h * w;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_grad_nchw<float>, grid1(total), dim3(256), 0, s, g, n, c, h, w, crop_w, mean_nc, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_grad_nchw<bf16_t>, grid1(total), dim3(256), 0, s, g, n, c, h, w, crop_w, mean_nc, (bf16_t*)out);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_sum_hw(const float* x, int32_t nc, int32_t hw, float scale, float* out, void* stream) {
+  if (!x || !out || nc <= 0 || hw <= 0) return MC_EINVAL;
+  hipLaunchKernelGGL(k_sum_hw, dim3(nc), dim3(256), 0, (hipStream_t)stream, x, hw, scale, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_finalize(const float* part, int32_t n, int32_t tiles, int32_t c, int32_t groups, int32_t hw, float eps,
+                   float* stats, float* chan_mean, void* stream) {
+  if (!part || n <= 0 || tiles <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || hw <= 0) return MC_EINVAL;
+  if (!stats && !chan_mean) return MC_EINVAL;
+  int CP = ((c + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_gn_finalize, dim3(groups, n), dim3(64), 0, (hipStream_t)stream, part, tiles, c, CP, groups, hw,
+                     eps, stats, chan_mean);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+static int fill_gn_args(GnArgs& a, int n, int c, int h, int w, int groups, const float* stats, const float* gamma,
+                        const float* beta, int post, int act) {
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MC_EINVAL;
+  if (post == MC_POST_GN_ACT && (groups <= 0 || c % groups != 0 || !stats || !gamma || !beta)) return MC_EINVAL;
+  if (post < MC_POST_NONE || post > MC_POST_GN_ACT || act < MC_ACT_NONE || act > MC_ACT_ELU) return MC_EINVAL;
+  a.N = n; a.C = c; a.C8 = (c + 7) / 8; a.H = h; a.W = w;
+  a.groups = groups > 0 ? groups : 1;
+  a.cpg = c / a.groups; a.post = post; a.act = act;
+  a.stats = stats; a.gamma = gamma; a.beta = beta;
+  return MC_OK;
+}
+
+int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
+                  const float* gamma, const float* beta, int32_t post, int32_t act, int32_t pool, int32_t dtype,
+                  void* a_out, void* pooled, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
+  if (rc) return rc;
+  if (!y || !a_out || (pool > 1 && !pooled)) return MC_EINVAL;
+  if (pool != 1 && pool != 2 && pool != 4) return MC_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int per = cdiv(h, pool) * cdiv(w, pool);
+  dim3 g = grid3(per, a.C8, n, 256, 4096);
+#define GN_LAUNCH(T, P) hipLaunchKernelGGL((k_gn_act_fwd<T, P>), g, dim3(256), 0, s, a, (const T*)y, (T*)a_out, (T*)pooled)
+  if (dtype == MC_F32) { if (pool == 1) GN_LAUNCH(float, 1); else if (pool == 2) GN_LAUNCH(float, 2); else GN_LAUNCH(float, 4); }
+  else if (dtype == MC_BF16) { if (pool == 1) GN_LAUNCH(bf16_t, 1); else if (pool == 2) GN_LAUNCH(bf16_t, 2); else GN_LAUNCH(bf16_t, 4); }
+  else return MC_EUNSUPPORTED;
+#undef GN_LAUNCH
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t f, int32_t dtype, void* out,
+                   void* stream) {
+  if (!x || !out || n <= 0 || c <= 0 || f < 1 || h < f || w < f) return MC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int C8 = (c + 7) / 8;
+  dim3 g = grid3((h / f) * (w / f), C8, n, 256, 4096);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_avgpool<float>, g, dim3(256), 0, s, (const float*)x, C8, h, w, f, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_avgpool<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, h, w, f, (bf16_t*)out);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int32_t mc_gn_bwd_blocks(int32_t h, int32_t w) {
+  int b = cdiv(h * w, 256 * 8);
+  if (b > 128) b = 128;
+  if (b < 1) b = 1;
+  return b;
+}
+
+static int check_gsrc(const mc_grad_src* g) {
+  if (!g) return MC_OK;
+  if (g->kind == MC_GSRC_NONE) return MC_OK;
+  if (!g->ptr || g->hs <= 0 || g->ws <= 0) return MC_EINVAL;
+  if (g->kind == MC_GSRC_PADFOLD_POOL && g->pool < 1) return MC_EINVAL;
+  if (g->kind != MC_GSRC_PLAIN && (g->pad < 0 || g->pad > 2)) return MC_EUNSUPPORTED;
+  return MC_OK;
+}
+static mc_grad_src gsrc_or_none(const mc_grad_src* g) {
+  mc_grad_src z;
+  z.ptr = nullptr; z.kind = MC_GSRC_NONE; z.pad = 0; z.pad_mode = 0; z.pool = 1; z.hs = 0; z.ws = 0;
+  return g ? *g : z;
+}
+
+int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
+                         const float* gamma, const float* beta, int32_t post, int32_t act, int32_t dtype,
+                         const mc_grad_src* g0, const mc_grad_src* g1, float* partials, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
+  if (rc) return rc;
+  if (post != MC_POST_GN_ACT || !y || !partials || !g0) return MC_EINVAL;
+  if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
+  dim3 g(mc_gn_bwd_blocks(h, w), a.C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_bwd_reduce<float>, g, dim3(256), 0, s, a, (const float*)y, gsrc_or_none(g0), gsrc_or_none(g1), partials, a.C8 * 8);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_bwd_reduce<bf16_t>, g, dim3(256), 0, s, a, (const bf16_t*)y, gsrc_or_none(g0), gsrc_or_none(g1), partials, a.C8 * 8);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_bwd_finalize(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups, int32_t hw,
+                           const float* gamma, float* m12, float* dgamma, float* dbeta, void* stream) {
+  if (!partials || n <= 0 || blocks <= 0 || c <= 0 || groups <= 0 || c % groups || hw <= 0) return MC_EINVAL;
+  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(groups), dim3(64), 0, (hipStream_t)stream, partials, n, blocks, c,
+                     ((c + 7) / 8) * 8, groups, hw, gamma, m12, dgamma, dbeta);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
+                        const float* m12, const float* gamma, const float* beta, int32_t post, int32_t act,
+                        int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
+  if (rc) return rc;
+  if (!y || !dy || !g0 || (post == MC_POST_GN_ACT && !m12)) return MC_EINVAL;
+  if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
+  if (post == MC_POST_NONE) a.act = MC_ACT_NONE;
+  dim3 g = grid3(h * w, a.C8, n, 256, 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_bwd_apply<float>, g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_bwd_apply<bf16_t>, g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_bicubic_fwd(const void* x, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                   const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x, const float* wgt_x, int32_t dtype,
+                   void* out, void* stream) {
+  if (!x || !out || !idx_y || !wgt_y || !idx_x || !wgt_x || n <= 0 || c <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0)
+    return MC_EINVAL;
+  int C8 = (c + 7) / 8;
+  dim3 g = grid3(ho * wo, C8, n, 256, 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_fwd<float>, g, dim3(256), 0, s, (const float*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_fwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (bf16_t*)out);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                   const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
+                   const float* txw, int32_t dtype, void* dx, void* stream) {
+  if (!gs || !dx || !tys || !tyj || !tyw || !txs || !txj || !txw || n <= 0 || c <= 0) return MC_EINVAL;
+  int rc = check_gsrc(gs);
+  if (rc) return rc;
+  if (gs->hs != ho || gs->ws != wo) return MC_EINVAL;
+  int C8 = (c + 7) / 8;
+  dim3 g = grid3(hi * wi, C8, n, 256, 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_bwd<float>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (float*)dx);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_bwd<bf16_t>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (bf16_t*)dx);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_curl_head_fwd(const float* a, const float* t_in, int32_t n, int32_t h, int32_t w, int64_t in_batch_stride,
+                     float a_bound, float t_lo, float t_hi, float* u, float* v, float* t_out, void* stream) {
+  if (!a || !u || !v || n <= 0 || h < 3 || w < 3 || ((t_in == nullptr) != (t_out == nullptr))) return MC_EINVAL;
+  dim3 g(min(cdiv(h * w, 256), 4096), n);
+  hipLaunchKernelGGL(k_curl_fwd, g, dim3(256), 0, (hipStream_t)stream, a, h, w, in_batch_stride, a_bound, u, v);
+  if (t_in) hipLaunchKernelGGL(k_clip_fwd, g, dim3(256), 0, (hipStream_t)stream, t_in, h * w, in_batch_stride, t_lo, t_hi, t_out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_curl_head_bwd(const float* gu, const float* gv, const float* gt_out, const float* t_in, int32_t n, int32_t h,
+                     int32_t w, float a_bound, float t_lo, float t_hi, float* ga, float* gt_in, int64_t g_batch_stride,
+                     int64_t in_batch_stride, float* ws, void* stream) {
+  if (!gu || !gv || !ga || !ws || n <= 0 || h < 3 || w < 3) return MC_EINVAL;
+  if (gt_in && (!gt_out || !t_in)) return MC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* eu = ws;
+  float* ev = ws + (size_t)n * (h - 2) * (w - 2);
+  dim3 g1(min(cdiv((h - 2) * (w - 2), 256), 4096), n);
+  hipLaunchKernelGGL(k_curl_bwd_fold, g1, dim3(256), 0, s, gu, gv, h, w, eu, ev);
+  dim3 g2(min(cdiv(h * w, 256), 4096), n);
+  hipLaunchKernelGGL(k_curl_bwd_stencil, g2, dim3(256), 0, s, eu, ev, h, w, a_bound, ga, g_batch_stride);
+  if (gt_in) hipLaunchKernelGGL(k_clip_bwd, g2, dim3(256), 0, s, gt_out, t_in, h * w, in_batch_stride, g_batch_stride, t_lo, t_hi, gt_in);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+}  // extern "C"

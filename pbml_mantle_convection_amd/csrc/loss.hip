@@ -1,0 +1,349 @@
+// Fused loss forward + backward (Trainer.loss_fn / get_loss, reference multigpu.py:122-134, 250-305)
+// and the build-defined Stokes momentum residual.  5-point stencil work on
+// [N][H][W] f32 fields: tiny next to the network, so neighbours are simply re-read through L1/L2.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sgn(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+
+__device__ __forceinline__ void block_add(double v, double* dst) {
+  // wave reduce, then one f64 atomic per wave
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
+}
+
+__global__ void k_minmax(const float* __restrict__ uvp, int ct, int hw, float* __restrict__ mm) {
+  const int n = blockIdx.x, f = blockIdx.y;  // f = 0 (u) or 1 (v)
+  const float* p = uvp + ((size_t)n * ct + f) * hw;
+  float lo = 3.4e38f, hi = -3.4e38f;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) { float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+  __shared__ float rl[4], rh[4];
+  if ((threadIdx.x & 63) == 0) { rl[threadIdx.x >> 6] = lo; rh[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[(n * 2 + f) * 2 + 0] = fminf(fminf(rl[0], rl[1]), fminf(rl[2], rl[3]));
+    mm[(n * 2 + f) * 2 + 1] = fmaxf(fmaxf(rh[0], rh[1]), fmaxf(rh[2], rh[3]));
+  }
+}
+
+struct LossGeom {
+  mc_loss_desc d;
+  int ct;           // channels of uvp
+  int64_t pbs;      // batch stride of the prediction planes
+};
+
+// weight(y,x) * sign(D(y,x)) of the divergence term, 0 outside the interior
+__device__ __forceinline__ float mass_wsgn(const LossGeom& g, const float* u, const float* v, int y, int x) {
+  const int H = g.d.h, W = g.d.w;
+  if (y < 1 || y > H - 2 || x < 1 || x > W - 2 || g.d.loss_type == 0) return 0.f;
+  float D = 0.5f * (u[(size_t)y * W + x + 1] - u[(size_t)y * W + x - 1]) +
+            0.5f * (v[(size_t)(y + 1) * W + x] - v[(size_t)(y - 1) * W + x]);
+  float w;
+  if (g.d.loss_type == 1) {
+    w = 1.0f / ((float)g.d.n * (float)(H - 2) * (float)(W - 2));
+  } else {
+    float wc = 1.0f / ((float)g.d.n * (float)(H - 2)), wr = 1.0f / ((float)g.d.n * (float)(W - 2));
+    w = (x == 1 ? wc : 0.f) + (x == W - 2 ? wc : 0.f) + (y == 1 ? wr : 0.f) + (y == H - 2 ? wr : 0.f);
+  }
+  return w * sgn(D);
+}
+
+__global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
+                                              const float* __restrict__ p_, const float* __restrict__ T_,
+                                              const float* __restrict__ uvp, const float* __restrict__ mm,
+                                              double* __restrict__ sums, float* __restrict__ gu_,
+                                              float* __restrict__ gv_, float* __restrict__ gp_,
+                                              float* __restrict__ gT_) {
+  const int H = g.d.h, W = g.d.w, HW = H * W, n = blockIdx.y;
+  const float* u = u_ + (size_t)n * g.pbs;
+  const float* v = v_ + (size_t)n * g.pbs;
+  const float* p = p_ ? p_ + (size_t)n * g.pbs : nullptr;
+  const float* T = T_ + (size_t)n * g.pbs;
+  const float* ut = uvp + ((size_t)n * g.ct + 0) * HW;
+  const float* vt = uvp + ((size_t)n * g.ct + 1) * HW;
+  const float* pt = g.d.p_pred ? uvp + ((size_t)n * g.ct + 2) * HW : nullptr;
+  const float* Tt = uvp + ((size_t)n * g.ct + (g.d.p_pred ? 3 : 2)) * HW;
+  const float k = g.d.p_pred ? 4.f : 3.f;
+  const float NHW = (float)g.d.n * (float)HW;
+  const float cdat = 1.0f / (k * NHW);
+  float su = 1.f, sv = 1.f;
+  if (g.d.loss_scale) {
+    su = fminf(fmaxf(1.0f / (mm[(n * 2 + 0) * 2 + 1] - mm[(n * 2 + 0) * 2 + 0]), 1.0f), 10.0f);
+    sv = fminf(fmaxf(1.0f / (mm[(n * 2 + 1) * 2 + 1] - mm[(n * 2 + 1) * 2 + 0]), 1.0f), 10.0f);
+  }
+  const float cdu = 126.0f / (k * (float)g.d.n * (float)(H - 2) * (float)W);
+  const float cdv = 126.0f / (k * (float)g.d.n * (float)H * (float)(W - 2));
+  double a_us = 0, a_up = 0, a_vs = 0, a_vp = 0, a_pp = 0, a_tp = 0, a_du = 0, a_dv = 0;
+  double a_m = 0, a_mx0 = 0, a_mx1 = 0, a_my0 = 0, a_my1 = 0;
+
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const int y = i / W, x = i % W;
+    const float bw = (g.d.loss_scale && (y < 2 || y >= H - 2 || x < 2 || x >= W - 2)) ? 11.f : 1.f;
+    float gu = 0.f, gv = 0.f, gp = 0.f, gT = 0.f;
+    {  // data terms
+      float du = ut[i] - u[i], dv = vt[i] - v[i], dT = Tt[i] - T[i];
+      float wu = su * bw, wv = sv * bw;
+      if (!g.d.l2) {
+        a_us += fabsf(du * wu); a_up += fabsf(du);
+        a_vs += fabsf(dv * wv); a_vp += fabsf(dv);
+        a_tp += fabsf(dT);
+        gu -= sgn(du) * wu * cdat; gv -= sgn(dv) * wv * cdat; gT -= sgn(dT) * cdat;
+      } else {
+        a_us += (double)(du * wu) * (du * wu); a_up += (double)du * du;
+        a_vs += (double)(dv * wv) * (dv * wv); a_vp += (double)dv * dv;
+        a_tp += (double)dT * dT;
+        gu -= 2.f * du * wu * wu * cdat; gv -= 2.f * dv * wv * wv * cdat; gT -= 2.f * dT * cdat;
+      }
+      if (p) {
+        float dp = pt[i] - p[i];
+        if (!g.d.l2) { a_pp += fabsf(dp); gp -= sgn(dp) * cdat; }
+        else { a_pp += (double)dp * dp; gp -= 2.f * dp * cdat; }
+      }
+    }
+    if (g.d.loss_derivative) {
+      // e_u[y'] = 126 ((ut[y'+1]-ut[y']) - (u[y'+1]-u[y'])), y' in [0,H-3]  (dy_top, multigpu.py:277-284)
+      if (y <= H - 3) {
+        float e = (ut[i + W] - ut[i]) - (u[i + W] - u[i]);
+        a_du += fabsf(126.0f * e);
+        gu += cdu * sgn(e);
+      }
+      if (y >= 1 && y <= H - 2) {
+        float e = (ut[i] - ut[i - W]) - (u[i] - u[i - W]);
+        gu -= cdu * sgn(e);
+      }
+      if (x <= W - 3) {
+        float e = (vt[i + 1] - vt[i]) - (v[i + 1] - v[i]);
+        a_dv += fabsf(126.0f * e);
+        gv += cdv * sgn(e);
+      }
+      if (x >= 1 && x <= W - 2) {
+        float e = (vt[i] - vt[i - 1]) - (v[i] - v[i - 1]);
+        gv -= cdv * sgn(e);
+      }
+    }
+    if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+      float D = 0.5f * (u[i + 1] - u[i - 1]) + 0.5f * (v[i + W] - v[i - W]);
+      float m = fabsf(D);
+      a_m += m;
+      if (x == 1) a_mx0 += m;
+      if (x == W - 2) a_mx1 += m;
+      if (y == 1) a_my0 += m;
+      if (y == H - 2) a_my1 += m;
+    }
+    if (g.d.loss_type != 0) {
+      gu += 0.5f * (mass_wsgn(g, u, v, y, x - 1) - mass_wsgn(g, u, v, y, x + 1));
+      gv += 0.5f * (mass_wsgn(g, u, v, y - 1, x) - mass_wsgn(g, u, v, y + 1, x));
+    }
+    gu_[(size_t)n * g.pbs + i] = gu;
+    gv_[(size_t)n * g.pbs + i] = gv;
+    if (gp_) gp_[(size_t)n * g.pbs + i] = gp;
+    if (gT_) gT_[(size_t)n * g.pbs + i] = g.d.t_grad ? gT : 0.f;
+  }
+  block_add(a_us, sums + MC_S_U_SCALED); block_add(a_up, sums + MC_S_U_PLAIN);
+  block_add(a_vs, sums + MC_S_V_SCALED); block_add(a_vp, sums + MC_S_V_PLAIN);
+  block_add(a_pp, sums + MC_S_P_PLAIN); block_add(a_tp, sums + MC_S_T_PLAIN);
+  block_add(a_du, sums + MC_S_DU); block_add(a_dv, sums + MC_S_DV);
+  block_add(a_m, sums + MC_S_MASS); block_add(a_mx0, sums + MC_S_MASS_X0); block_add(a_mx1, sums + MC_S_MASS_X1);
+  block_add(a_my0, sums + MC_S_MASS_Y0); block_add(a_my1, sums + MC_S_MASS_Y1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// momentum residual
+// ------------------------------------------------------------------------------------------------
+struct MomGeom {
+  int N, H, W;
+  int64_t pbs;
+  float ih, ra, lam;
+};
+
+struct MomField {
+  const float* T; const float* yc; float lnfkt, lnfkp; int H, W;
+  __device__ __forceinline__ float eta(int i, int j) const {
+    float e = expf(-lnfkt * T[(size_t)i * W + j] + lnfkp * (1.0f - yc[(size_t)i * W + j]));
+    return fminf(fmaxf(e, 1e-8f), 1.0f);
+  }
+  __device__ __forceinline__ float exf(int i, int j) const {  // x-face (i, j+1/2)
+    if (i < 0 || i >= H || j < 0 || j > W - 2) return 0.f;
+    return 0.5f * (eta(i, j) + eta(i, j + 1));
+  }
+  __device__ __forceinline__ float eyf(int i, int j) const {  // y-face (i+1/2, j)
+    if (i < 0 || i > H - 2 || j < 0 || j >= W) return 0.f;
+    return 0.5f * (eta(i, j) + eta(i + 1, j));
+  }
+};
+
+__global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
+                                                      const float* __restrict__ p_, const float* __restrict__ T_,
+                                                      const float* __restrict__ yc, const float* __restrict__ paras,
+                                                      const float* __restrict__ scaler, double* __restrict__ sums,
+                                                      float* __restrict__ sx_, float* __restrict__ sy_) {
+  const int H = g.H, W = g.W, HW = H * W, n = blockIdx.y;
+  const float* u = u_ + (size_t)n * g.pbs;
+  const float* v = v_ + (size_t)n * g.pbs;
+  const float* p = p_ ? p_ + (size_t)n * g.pbs : nullptr;
+  const float* T = T_ + (size_t)n * g.pbs;
+  MomField f{T, yc, logf(paras[n * 3 + 1]), logf(paras[n * 3 + 2]), H, W};
+  const float s = scaler[n], ih = g.ih;
+  const float c = g.lam / ((float)g.N * (float)(H - 2) * (float)(W - 2));
+  double ax = 0, ay = 0;
+  auto U = [&](int i, int j) { return s * u[(size_t)i * W + j]; };
+  auto V = [&](int i, int j) { return s * v[(size_t)i * W + j]; };
+  auto P = [&](int i, int j) { return p ? p[(size_t)i * W + j] : 0.f; };
+  auto dVdx = [&](int i, int j) { return 0.5f * (V(i, j + 1) - V(i, j - 1)) * ih; };
+  auto dUdy = [&](int i, int j) { return 0.5f * (U(i + 1, j) - U(i - 1, j)) * ih; };
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += gridDim.x * blockDim.x) {
+    const int i = idx / W, j = idx % W;
+    float ox = 0.f, oy = 0.f;
+    if (i >= 1 && i <= H - 2 && j >= 1 && j <= W - 2) {
+      float Fx1 = 2.f * f.exf(i, j) * (U(i, j + 1) - U(i, j)) * ih;
+      float Fx0 = 2.f * f.exf(i, j - 1) * (U(i, j) - U(i, j - 1)) * ih;
+      float Ty1 = f.eyf(i, j) * ((U(i + 1, j) - U(i, j)) * ih + 0.5f * (dVdx(i, j) + dVdx(i + 1, j)));
+      float Ty0 = f.eyf(i - 1, j) * ((U(i, j) - U(i - 1, j)) * ih + 0.5f * (dVdx(i - 1, j) + dVdx(i, j)));
+      float Rx = -0.5f * (P(i, j + 1) - P(i, j - 1)) * ih + (Fx1 - Fx0) * ih + (Ty1 - Ty0) * ih;
+      float Fy1 = 2.f * f.eyf(i, j) * (V(i + 1, j) - V(i, j)) * ih;
+      float Fy0 = 2.f * f.eyf(i - 1, j) * (V(i, j) - V(i - 1, j)) * ih;
+      float Tx1 = f.exf(i, j) * ((V(i, j + 1) - V(i, j)) * ih + 0.5f * (dUdy(i, j) + dUdy(i, j + 1)));
+      float Tx0 = f.exf(i, j - 1) * ((V(i, j) - V(i, j - 1)) * ih + 0.5f * (dUdy(i, j - 1) + dUdy(i, j)));
+      float Ry = -0.5f * (P(i + 1, j) - P(i - 1, j)) * ih + (Fy1 - Fy0) * ih + (Tx1 - Tx0) * ih + g.ra * T[idx];
+      ax += fabsf(Rx); ay += fabsf(Ry);
+      ox = c * sgn(Rx); oy = c * sgn(Ry);
+    }
+    sx_[(size_t)n * HW + idx] = ox;
+    sy_[(size_t)n * HW + idx] = oy;
+  }
+  block_add(ax, sums + MC_S_MOMX);
+  block_add(ay, sums + MC_S_MOMY);
+}
+
+__global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ T_, const float* __restrict__ yc,
+                                                     const float* __restrict__ paras, const float* __restrict__ scaler,
+                                                     const float* __restrict__ sx_, const float* __restrict__ sy_,
+                                                     float* __restrict__ gu_, float* __restrict__ gv_,
+                                                     float* __restrict__ gp_, float* __restrict__ gT_, int t_grad) {
+  const int H = g.H, W = g.W, HW = H * W, n = blockIdx.y;
+  const float* T = T_ + (size_t)n * g.pbs;
+  const float* sx = sx_ + (size_t)n * HW;
+  const float* sy = sy_ + (size_t)n * HW;
+  MomField f{T, yc, logf(paras[n * 3 + 1]), logf(paras[n * 3 + 2]), H, W};
+  const float s = scaler[n], ih = g.ih;
+  auto SX = [&](int i, int j) { return (i < 0 || i >= H || j < 0 || j >= W) ? 0.f : sx[(size_t)i * W + j]; };
+  auto SY = [&](int i, int j) { return (i < 0 || i >= H || j < 0 || j >= W) ? 0.f : sy[(size_t)i * W + j]; };
+  // adjoint face quantities (zero outside their domains because S is zero-extended)
+  auto dFx = [&](int i, int j) { return ih * (SX(i, j) - SX(i, j + 1)); };
+  auto dTy = [&](int i, int j) { return ih * (SX(i, j) - SX(i + 1, j)); };
+  auto dFy = [&](int i, int j) { return ih * (SY(i, j) - SY(i + 1, j)); };
+  auto dTx = [&](int i, int j) { return ih * (SY(i, j) - SY(i, j + 1)); };
+  auto E = [&](int i, int j) { return f.eyf(i, j) * dTy(i, j); };   // eyf = 0 outside the y-face domain
+  auto Fh = [&](int i, int j) { return f.exf(i, j) * dTx(i, j); };
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += gridDim.x * blockDim.x) {
+    const int i = idx / W, j = idx % W;
+    float dU = 2.f * ih * (f.exf(i, j - 1) * dFx(i, j - 1) - f.exf(i, j) * dFx(i, j))
+             + ih * (E(i - 1, j) - E(i, j))
+             + 0.25f * ih * (Fh(i - 1, j) - Fh(i + 1, j) + Fh(i - 1, j - 1) - Fh(i + 1, j - 1));
+    float dV = 2.f * ih * (f.eyf(i - 1, j) * dFy(i - 1, j) - f.eyf(i, j) * dFy(i, j))
+             + ih * (Fh(i, j - 1) - Fh(i, j))
+             + 0.25f * ih * (E(i, j - 1) - E(i, j + 1) + E(i - 1, j - 1) - E(i - 1, j + 1));
+    float dP = -0.5f * ih * (SX(i, j - 1) - SX(i, j + 1)) - 0.5f * ih * (SY(i - 1, j) - SY(i + 1, j));
+    gu_[(size_t)n * g.pbs + idx] += s * dU;
+    gv_[(size_t)n * g.pbs + idx] += s * dV;
+    if (gp_) gp_[(size_t)n * g.pbs + idx] += dP;
+    if (gT_ && t_grad) gT_[(size_t)n * g.pbs + idx] += g.ra * SY(i, j);
+  }
+}
+
+__global__ void k_loss_finalize(mc_loss_desc d, const double* __restrict__ s, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double N = d.n, H = d.h, W = d.w, NHW = N * H * W;
+  double lu = s[MC_S_U_SCALED] / NHW, lv = s[MC_S_V_SCALED] / NHW;
+  double tu = s[MC_S_U_PLAIN] / NHW, tv = s[MC_S_V_PLAIN] / NHW;
+  if (!d.loss_scale) { lu = tu; lv = tv; }
+  double lp = d.p_pred ? s[MC_S_P_PLAIN] / NHW : 0.0, lT = s[MC_S_T_PLAIN] / NHW;
+  if (d.loss_derivative) {
+    lu += s[MC_S_DU] / (N * (H - 2) * W);
+    lv += s[MC_S_DV] / (N * H * (W - 2));
+    if (!d.loss_scale) { tu = lu; tv = lv; }   // reference aliasing quirk (multigpu.py:283-284)
+  }
+  double loss = d.p_pred ? (lu + lv + lp + lT) / 4.0 : (lu + lv + lT) / 3.0;
+  double mass = s[MC_S_MASS] / (N * (H - 2) * (W - 2));
+  if (d.loss_type == 1) loss += mass;
+  else if (d.loss_type == 2)
+    loss += (s[MC_S_MASS_X0] + s[MC_S_MASS_X1]) / (N * (H - 2)) + (s[MC_S_MASS_Y0] + s[MC_S_MASS_Y1]) / (N * (W - 2));
+  double mom = (s[MC_S_MOMX] + s[MC_S_MOMY]) / (N * (H - 2) * (W - 2));
+  if (d.lambda_mom != 0.f) loss += (double)d.lambda_mom * mom;
+  out[0] = (float)loss; out[1] = (float)tu; out[2] = (float)tv; out[3] = (float)lp; out[4] = (float)lT;
+  out[5] = (float)mass; out[6] = (float)mom; out[7] = 0.f;
+}
+
+int check_loss_desc(const mc_loss_desc* d) {
+  if (!d || d->n <= 0 || d->h < 5 || d->w < 5) return MC_EINVAL;
+  if (d->loss_type < 0 || d->loss_type > 2) return MC_EINVAL;
+  return MC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w, float* mm, void* stream) {
+  if (!uvp || !mm || n <= 0 || ct < 2 || h <= 0 || w <= 0) return MC_EINVAL;
+  hipLaunchKernelGGL(k_minmax, dim3(n, 2), dim3(256), 0, (hipStream_t)stream, uvp, ct, h * w, mm);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
+                    int64_t pbs, const float* uvp, const float* mm, double* sums, float* gu, float* gv, float* gp,
+                    float* gT, void* stream) {
+  int rc = check_loss_desc(d);
+  if (rc) return rc;
+  if (!u || !v || !T || !uvp || !sums || !gu || !gv || !gT) return MC_EINVAL;
+  if (d->p_pred && (!p || !gp)) return MC_EINVAL;
+  if (d->loss_scale && !mm) return MC_EINVAL;
+  LossGeom g;
+  g.d = *d; g.ct = d->p_pred ? 4 : 3; g.pbs = pbs;
+  dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
+  hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
+                     gu, gv, d->p_pred ? gp : nullptr, gT);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
+                         int64_t pbs, const float* yc, const float* paras, const float* scaler, double* sums,
+                         float* sx, float* sy, void* stream) {
+  int rc = check_loss_desc(d);
+  if (rc) return rc;
+  if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy) return MC_EINVAL;
+  MomGeom g{d->n, d->h, d->w, pbs, d->inv_h, d->ra, d->lambda_mom};
+  dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
+  hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, yc, paras, scaler, sums, sx, sy);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, const float* yc, const float* paras,
+                        const float* scaler, const float* sx, const float* sy, float* gu, float* gv, float* gp,
+                        float* gT, void* stream) {
+  int rc = check_loss_desc(d);
+  if (rc) return rc;
+  if (!T || !yc || !paras || !scaler || !sx || !sy || !gu || !gv) return MC_EINVAL;
+  MomGeom g{d->n, d->h, d->w, pbs, d->inv_h, d->ra, d->lambda_mom};
+  dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
+  hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, T, yc, paras, scaler, sx, sy, gu, gv, gp, gT,
+                     d->t_grad);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_loss_finalize(const mc_loss_desc* d, const double* sums, float* out8, void* stream) {
+  int rc = check_loss_desc(d);
+  if (rc) return rc;
+  if (!sums || !out8) return MC_EINVAL;
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, *d, sums, out8);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,511 @@
+"""Host-side executor of the Stokes-surrogate network on libmantle_hip (MI355X).
+
+A network (Unet, ConvAE, or a single layer) is described as a small static graph of
+conv / upsample nodes (`NetGraph`).  `Engine` resolves shapes for a given input size, owns
+every device buffer (activations in the CB8 layout, GroupNorm statistics, filter banks,
+gradient buffers, workspaces) and issues the C-ABI kernel calls for forward and backward
+on the current HIP stream — so a whole training step can be captured into one HIP graph.
+
+Reference call sites replaced: Unet.forward (pytorch_networks_convae.py:1985-2070),
+ConvAE.forward (.ipynb_checkpoints/pycold-checkpoint.py:1094-1115), FluidLayer.forward
+(:790-799) and the autograd backward of all of them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+DTYPES = {"fp32": (L.MC_F32, torch.float32), "f32": (L.MC_F32, torch.float32),
+          "bf16": (L.MC_BF16, torch.bfloat16)}
+
+
+# ------------------------------------------------------------------------------------------------
+# static graph
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ConvNode:
+    name: str                  # state-dict prefix of the conv weight/bias ("conv.0.layers.0." ...)
+    srcs: List[int]            # tensor ids (1 or 2: torch.cat order)
+    out: int                   # tensor id of the activated output
+    c_out: int
+    k: int
+    pad: int
+    sym_h: int                 # 0 = plain nn.Conv2d
+    post: int                  # L.POST_*
+    gn_name: Optional[str]     # state-dict prefix of the GroupNorm affine or None
+    groups: int
+    pool: int = 1              # AvgPool factor applied to the activated output (1 = none)
+    pooled: int = -1           # tensor id of the pooled output
+    kind: str = "conv"
+
+
+@dataclass
+class UpNode:
+    src: int
+    out: int
+    size: Optional[Tuple[int, int]] = None   # resolved at plan time (size of a named tensor)
+    like: int = -1                           # take H, W of this tensor id ...
+    scale: int = 0                           # ... or multiply by this integer scale factor
+    kind: str = "up"
+
+
+@dataclass
+class NetGraph:
+    c_in: int
+    c_out: int
+    channels: Dict[int, int]   # tensor id -> channel count
+    nodes: list
+    in_pad_w: int = 0          # F.pad(inputs, (3,3,0,0)) of the Unet
+    crop_w: int = 0            # [..., 3:-3]
+    subtract_mean: bool = False
+    pad_mode: str = "zeros"
+    act: str = "gelu"
+    divisor: int = 1           # H, W must be divisible by this (ConvAE: 4**levels)
+
+
+def _sym_h(c_o: int) -> int:
+    # FluidLayer: h = c_o/4 (c_o/2 if c_o <= 4), v = hv = 0 (reference pytorch_networks_convae.py:755-757)
+    return int(c_o / 4) if c_o > 4 else int(c_o / 2)
+
+
+def _groups(c_o: int) -> int:
+    return int(c_o / min(4, c_o))   # :788
+
+
+def unet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f) -> NetGraph:
+    """Layer wiring of Unet.__init__/forward (reference pytorch_networks_convae.py:1842-2024)."""
+    ch: Dict[int, int] = {0: c_i}
+    nodes = []
+    nid = [0]
+
+    def new(c):
+        nid[0] += 1
+        ch[nid[0]] = c
+        return nid[0]
+
+    def fluid(prefix, srcs, c_out, pool=1):
+        out = new(c_out)
+        node = ConvNode(prefix + "layers.0.", list(srcs), out, c_out, f, f // 2, _sym_h(c_out) if use_symm else 0,
+                        L.POST_GN_ACT, prefix + "layers.1.", _groups(c_out), pool)
+        if pool > 1:
+            node.pooled = new(c_out)
+        nodes.append(node)
+        return node
+
+    feat = {}
+    cur = 0
+    for r in range(repeats):
+        last = r == repeats - 1
+        n = fluid(f"conv.{r}.", [cur], c_h, pool=2 if (last and levels > 1) else 1)
+        cur = n.out
+    feat[0] = n
+    c = c_h
+    for l in range(1, levels):
+        cur = feat[l - 1].pooled
+        for r in range(repeats):
+            last = r == repeats - 1
+            n = fluid(f"convs.{l - 1}.{r}.", [cur], c, pool=2 if (last and l < levels - 1) else 1)
+            cur = n.out
+        feat[l] = n
+        c *= 2
+    c = int(c / 2)
+    xu = feat[levels - 1].out
+    for li, l in enumerate(range(levels - 2, 0, -1)):
+        up = new(ch[xu])
+        nodes.append(UpNode(xu, up, like=feat[l].out))
+        srcs = [feat[l].out, up]
+        for r in range(repeats):
+            n = fluid(f"upconvs.{li}.{r}.", srcs, int(c / 2))
+            srcs = [n.out]
+        xu = n.out
+        c = int(c / 2)
+    if levels > 1:
+        up = new(ch[xu])
+        nodes.append(UpNode(xu, up, like=feat[0].out))
+        head_srcs = [up, feat[0].out]
+    else:
+        raise ValueError("Unet needs levels >= 2")
+    R = repeats
+    o = new(c)
+    nodes.append(ConvNode(f"conv.{R}.", head_srcs, o, c, f, f // 2, 0, L.POST_GN_ACT, "gn.0.", int(c / 4)))
+    o2 = new(c)
+    nodes.append(ConvNode(f"conv.{R + 1}.", [o], o2, c, f, f // 2, 0, L.POST_ACT, None, 1))
+    o3 = new(c_o)
+    nodes.append(ConvNode(f"conv.{R + 2}.", [o2], o3, c_o, f, f // 2, 0, L.POST_NONE, None, 1))
+    return NetGraph(c_i, c_o, ch, nodes, in_pad_w=3, crop_w=3, subtract_mean=True, pad_mode=r_p, act=act,
+                    divisor=1)
+
+
+def convae_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, loss_type) -> NetGraph:
+    """ConvAE.__init__ (reference .ipynb_checkpoints/pycold-checkpoint.py:1038-1092); returns the graph and
+    keeps the ModuleList indices of the reference (pool / upsample modules consume an index)."""
+    ch: Dict[int, int] = {0: c_i}
+    nodes = []
+    nid = [0]
+    idx = [0]
+
+    def new(c):
+        nid[0] += 1
+        ch[nid[0]] = c
+        return nid[0]
+
+    def fluid(src, c_out):
+        out = new(c_out)
+        p = f"conv.{idx[0]}."
+        idx[0] += 1
+        node = ConvNode(p + "layers.0.", [src], out, c_out, f, f // 2, _sym_h(c_out) if use_symm else 0,
+                        L.POST_GN_ACT, p + "layers.1.", _groups(c_out))
+        nodes.append(node)
+        return node
+
+    n = fluid(0, c_h)
+    c = c_h
+    for _ in range(levels):
+        n.pool = 4
+        n.pooled = new(n.c_out)
+        idx[0] += 1                       # the AvgPool2d module
+        cur = n.pooled
+        cout = c * 4
+        for r in range(repeats):
+            n = fluid(cur, int(cout))
+            cur = n.out
+        c *= 4
+    c = int(c / 4)
+    cur = n.out
+    for r in range(repeats):
+        n = fluid(cur, c)
+        cur = n.out
+    for _ in range(levels, 0, -1):
+        up = new(ch[cur])
+        nodes.append(UpNode(cur, up, scale=4))
+        idx[0] += 1                       # the Upsample module
+        cur = up
+        cout = int(c / 4)
+        for r in range(repeats):
+            n = fluid(cur, cout)
+            cur = n.out
+        c = int(c / 4)
+    o = new(c_o)
+    nodes.append(ConvNode(f"conv.{idx[0]}.", [cur], o, int(c_o), 3, 2 if loss_type == "curl" else 1, 0, L.POST_NONE,
+                          None, 1))
+    return NetGraph(c_i, int(c_o), ch, nodes, pad_mode=r_p, act=act, divisor=4 ** levels)
+
+
+def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool) -> NetGraph:
+    """One conv (+GN+act): SymmetricConv2d / FluidLayer used stand-alone."""
+    ch = {0: c_in, 1: c_out}
+    node = ConvNode("layers.0." if gn else "", [0], 1, c_out, k, pad, sym_h, post, "layers.1." if gn else None, groups)
+    return NetGraph(c_in, c_out, ch, [node], pad_mode=pad_mode, act=act)
+
+
+# ------------------------------------------------------------------------------------------------
+# bicubic tap tables (nn.Upsample(mode='bicubic', align_corners=False), A = -0.75), built in f64
+# ------------------------------------------------------------------------------------------------
+def bicubic_tables(n_in: int, n_out: int):
+    A = -0.75
+    scale = n_in / n_out
+    o = np.arange(n_out, dtype=np.float64)
+    real = scale * (o + 0.5) - 0.5
+    i0 = np.floor(real)
+    t = real - i0
+
+    def c1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def c2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    w = np.stack([c2(t + 1), c1(t), c1(1 - t), c2(2 - t)], 1)
+    idx = np.clip(i0[:, None] + np.arange(-1, 3)[None, :], 0, n_in - 1).astype(np.int32)
+    # transposed (CSR over input index)
+    lists = [dict() for _ in range(n_in)]
+    for oo in range(n_out):
+        for k in range(4):
+            d = lists[idx[oo, k]]
+            d[oo] = d.get(oo, 0.0) + w[oo, k]
+    start = np.zeros(n_in + 1, np.int32)
+    tj, tw = [], []
+    for i in range(n_in):
+        for oo in sorted(lists[i]):
+            tj.append(oo)
+            tw.append(lists[i][oo])
+        start[i + 1] = len(tj)
+    return (idx, w.astype(np.float32), start, np.asarray(tj, np.int32), np.asarray(tw, np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# engine
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class _T:            # runtime tensor
+    C: int
+    H: int = 0
+    W: int = 0
+    buf: Optional[torch.Tensor] = None
+    requires_grad: bool = True
+    gsrcs: list = field(default_factory=list)   # gradient sources registered during backward
+
+
+class Engine:
+    """Executes a NetGraph.  `params` maps state-dict names to f32 device tensors;
+    `grads` maps the same names to f32 device tensors that backward ACCUMULATES into."""
+
+    def __init__(self, graph: NetGraph, precision: str = "fp32"):
+        if precision not in DTYPES:
+            raise ValueError(f"precision must be one of {list(DTYPES)}")
+        L.load()
+        self.g = graph
+        self.precision = "fp32" if precision == "f32" else precision
+        self.mc_dtype, self.t_dtype = DTYPES[precision]
+        self.shape = None
+        self._tables = {}
+
+    # -------------------------------------------------------------- planning
+    def configure(self, N: int, H: int, W: int, device):
+        if self.shape == (N, H, W, str(device)):
+            return
+        g = self.g
+        if H % g.divisor or W % g.divisor:
+            raise ValueError(f"input H, W must be divisible by {g.divisor}")
+        self.device = device
+        self.N = N
+        T: Dict[int, _T] = {tid: _T(C=c) for tid, c in g.channels.items()}
+        T[0].H, T[0].W, T[0].requires_grad = H, W + 2 * g.in_pad_w, False
+        mode = L.PAD_MODES[g.pad_mode]
+        self.mode = mode
+        f32 = dict(dtype=torch.float32, device=device)
+        self.plan = []
+        max_dy = 0
+        max_wg = 0
+
+        def cb8(c, h, w):
+            return torch.empty((N, (c + 7) // 8, h, w, 8), dtype=self.t_dtype, device=device)
+
+        T[0].buf = cb8(T[0].C, T[0].H, T[0].W)
+        for node in g.nodes:
+            if node.kind == "up":
+                s = T[node.src]
+                if node.like >= 0:
+                    ho, wo = T[node.like].H, T[node.like].W
+                else:
+                    ho, wo = s.H * node.scale, s.W * node.scale
+                o = T[node.out]
+                o.H, o.W = ho, wo
+                o.buf = cb8(o.C, ho, wo)
+                tabs = (self._table(s.H, ho), self._table(s.W, wo))
+                self.plan.append(dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W)))
+                continue
+            srcs = [T[i] for i in node.srcs]
+            h, w = srcs[0].H, srcs[0].W
+            for s in srcs:
+                assert (s.H, s.W) == (h, w), "concat sources must agree in size"
+            d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
+                           mode, self.mc_dtype, node.sym_h, 0)
+            ho, wo = h + 2 * node.pad - node.k + 1, w + 2 * node.pad - node.k + 1
+            o = T[node.out]
+            o.H, o.W = ho, wo
+            tiles = L.call("mc_conv_tiles", C.byref(d))
+            if tiles <= 0:
+                raise L.MantleHipError(f"unsupported convolution configuration for {node.name} "
+                                       f"({self.precision}, c_in={srcs[0].C}+{d.c_in1}, c_out={node.c_out}, k={node.k})")
+            coutp = ((node.c_out + 7) // 8) * 8
+            cin_tot = sum(s.C for s in srcs)
+            # dgrad = the same kernel on the padded domain: zero pad k-1, rotated/transposed bank
+            dd = L.ConvDesc(N, ho, wo, node.c_out, 0, cin_tot, node.k, node.k - 1, 0, self.mc_dtype, 0,
+                            srcs[0].C if len(srcs) > 1 else 0)
+            need_dgrad = any(s.requires_grad for s in srcs)
+            e = dict(node=node, desc=d, ddesc=dd, tiles=tiles, coutp=coutp,
+                     Y=cb8(node.c_out, ho, wo),
+                     part=torch.empty((N, tiles, coutp, 2), **f32),
+                     bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
+                     need_dgrad=need_dgrad)
+            if node.post != L.POST_NONE:
+                o.buf = cb8(node.c_out, ho, wo)
+            else:
+                o.buf = e["Y"]
+            if node.post == L.POST_GN_ACT:
+                e["stats"] = torch.empty((N, node.groups, 2), **f32)
+                blocks = L.call("mc_gn_bwd_blocks", ho, wo)
+                e["gblocks"] = blocks
+                e["gpart"] = torch.empty((N, blocks, coutp, 2), **f32)
+                e["m12"] = torch.empty((N, node.groups, 2), **f32)
+            if node.pool > 1:
+                p = T[node.pooled]
+                p.H, p.W = ho // node.pool, wo // node.pool
+                p.buf = cb8(node.c_out, p.H, p.W)
+            if need_dgrad:
+                e["dbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 1), dtype=torch.uint8,
+                                         device=device)
+                hp, wp = h + 2 * node.pad, w + 2 * node.pad
+                e["dxp"] = [cb8(s.C, hp, wp) for s in srcs]
+            max_dy = max(max_dy, N * coutp * ho * wo)
+            max_wg = max(max_wg, L.call("mc_wgrad_partial_bytes", C.byref(d)))
+            self.plan.append(e)
+        self.T = T
+        self.dY = torch.empty(max_dy, dtype=self.t_dtype, device=device)
+        self.wg_part = torch.empty(max_wg, dtype=torch.uint8, device=device)
+        last = self.plan[-1]
+        assert last["node"].kind == "conv", "graph must end in a conv node"
+        self.final_plain = last["node"].post == L.POST_NONE
+        assert self.final_plain or not g.subtract_mean
+        fo = T[last["node"].out]
+        self.out_h, self.out_w = fo.H, fo.W - 2 * g.crop_w
+        self.dOut = None if self.final_plain else cb8(fo.C, fo.H, fo.W)
+        self.chan_mean = torch.empty((N, g.c_out), **f32) if g.subtract_mean else None
+        self.gmean = torch.empty((N, g.c_out), **f32) if g.subtract_mean else None
+        self.shape = (N, H, W, str(device))
+
+    def _table(self, n_in, n_out):
+        key = (n_in, n_out)
+        if key not in self._tables:
+            self._tables[key] = tuple(torch.from_numpy(a).to(self.device) for a in bicubic_tables(n_in, n_out))
+        return self._tables[key]
+
+    # -------------------------------------------------------------- forward
+    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """x: [N, c_in, H, W] f32 device tensor -> [N, c_out, H', W'] f32."""
+        L.require_cuda(x, "network input")
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        N, Ci, H, W = x.shape
+        if Ci != self.g.c_in:
+            raise ValueError(f"expected {self.g.c_in} input channels, got {Ci}")
+        self.configure(N, H, W, x.device)
+        st = L.stream()
+        g, T = self.g, self.T
+        act = L.ACTS[g.act]
+        L.call("mc_pack_nchw", L.ptr(x), N, Ci, H, W, g.in_pad_w, self.mode, self.mc_dtype, L.ptr(T[0].buf), st)
+        for e in self.plan:
+            node = e["node"]
+            if node.kind == "up":
+                s, o = T[node.src], T[node.out]
+                (iy, wy, *_), (ix, wx, *_) = e["tabs"]
+                L.call("mc_bicubic_fwd", L.ptr(s.buf), N, s.C, s.H, s.W, o.H, o.W, L.ptr(iy), L.ptr(wy), L.ptr(ix),
+                       L.ptr(wx), self.mc_dtype, L.ptr(o.buf), st)
+                continue
+            d = e["desc"]
+            w = self._param(params, node.name + "weight")
+            b = self._param(params, node.name + "bias")
+            L.call("mc_pack_weights", C.byref(d), L.ptr(w), 0, L.ptr(e["bank"]), st)
+            srcs = [T[i] for i in node.srcs]
+            o = T[node.out]
+            final = node.post == L.POST_NONE
+            need_part = node.post == L.POST_GN_ACT or (final and g.subtract_mean)
+            L.call("mc_conv2d", C.byref(d), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf) if len(srcs) > 1 else None,
+                   L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None, L.ptr(e["part"]) if need_part else None, st)
+            if node.post == L.POST_GN_ACT:
+                L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
+                       L.ptr(e["stats"]), None, st)
+            if not final:
+                gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
+                beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
+                pooled = T[node.pooled].buf if node.pool > 1 else None
+                L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                       L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype,
+                       L.ptr(o.buf), L.ptr(pooled), st)
+            elif g.subtract_mean:
+                L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, 1, o.H * o.W, 1e-5, None,
+                       L.ptr(self.chan_mean), st)
+        fo = T[self.plan[-1]["node"].out]
+        out = torch.empty((N, g.c_out, self.out_h, self.out_w), dtype=torch.float32, device=x.device)
+        L.call("mc_unpack_nchw", L.ptr(fo.buf), N, fo.C, fo.H, fo.W, g.crop_w, L.ptr(self.chan_mean), self.mc_dtype,
+               L.ptr(out), st)
+        return out
+
+    @staticmethod
+    def _param(params, name):
+        p = params[name]
+        if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+            raise RuntimeError(f"parameter {name} must be a contiguous f32 device tensor")
+        return p
+
+    # -------------------------------------------------------------- backward
+    def backward(self, gout: torch.Tensor, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]):
+        """gout: d(loss)/d(output) [N, c_out, H', W'] f32.  Accumulates parameter gradients into `grads`."""
+        L.require_cuda(gout, "output gradient")
+        gout = gout.contiguous().float()
+        g, T, N = self.g, self.T, self.N
+        st = L.stream()
+        act = L.ACTS[g.act]
+        for t in T.values():
+            t.gsrcs = []
+        fo = T[self.plan[-1]["node"].out]
+        mean = None
+        if g.subtract_mean:
+            L.call("mc_sum_hw", L.ptr(gout), N * g.c_out, self.out_h * self.out_w, 1.0 / (fo.H * fo.W),
+                   L.ptr(self.gmean), st)
+            mean = self.gmean
+        gdst = self.dY if self.final_plain else self.dOut
+        L.call("mc_pack_grad_nchw", L.ptr(gout), N, g.c_out, fo.H, fo.W, g.crop_w, L.ptr(mean), self.mc_dtype,
+               L.ptr(gdst), st)
+        if not self.final_plain:
+            fo.gsrcs.append(L.GradSrc(L.ptr(self.dOut), L.GSRC_PLAIN, 0, 0, 1, fo.H, fo.W))
+        for e in reversed(self.plan):
+            node = e["node"]
+            if node.kind == "up":
+                s, o = T[node.src], T[node.out]
+                assert len(o.gsrcs) == 1, "an upsampled tensor feeds exactly one conv"
+                (_, _, tys, tyj, tyw), (_, _, txs, txj, txw) = e["tabs"]
+                L.call("mc_bicubic_bwd", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
+                       L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["dsrc"]), st)
+                s.gsrcs.append(L.GradSrc(L.ptr(e["dsrc"]), L.GSRC_PLAIN, 0, 0, 1, s.H, s.W))
+                continue
+            d = e["desc"]
+            o = T[node.out]
+            srcs = [T[i] for i in node.srcs]
+            dY = self.dY
+            if node.post != L.POST_NONE:
+                gs = list(o.gsrcs)
+                if node.pool > 1:
+                    p = T[node.pooled]
+                    for q in p.gsrcs:
+                        assert q.kind == L.GSRC_PADFOLD, "a pooled tensor feeds exactly one conv"
+                        gs.append(L.GradSrc(q.ptr, L.GSRC_PADFOLD_POOL, q.pad, q.pad_mode, node.pool, p.H, p.W))
+                assert 1 <= len(gs) <= 2, f"{node.name}: {len(gs)} gradient sources"
+                g0 = C.byref(gs[0])
+                g1 = C.byref(gs[1]) if len(gs) > 1 else None
+                gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
+                beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
+                if node.post == L.POST_GN_ACT:
+                    L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                           L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
+                           L.ptr(e["gpart"]), st)
+                    L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
+                           o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
+                           L.ptr(grads[node.gn_name + "bias"]), st)
+                L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                       L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
+                       self.mc_dtype, g0, g1, L.ptr(dY), st)
+            x0 = L.ptr(srcs[0].buf)
+            x1 = L.ptr(srcs[1].buf) if len(srcs) > 1 else None
+            L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(self.wg_part), st)
+            L.call("mc_conv2d_wgrad_finalize", C.byref(d), L.ptr(self.wg_part), L.ptr(grads[node.name + "weight"]),
+                   L.ptr(grads[node.name + "bias"]), st)
+            if e["need_dgrad"]:
+                w = self._param(params, node.name + "weight")
+                L.call("mc_pack_weights", C.byref(d), L.ptr(w), 1, L.ptr(e["dbank"]), st)
+                dxp = e["dxp"]
+                L.call("mc_conv2d", C.byref(e["ddesc"]), L.ptr(dY), None, L.ptr(e["dbank"]), None, L.ptr(dxp[0]),
+                       L.ptr(dxp[1]) if len(dxp) > 1 else None, None, st)
+                for s, buf in zip(srcs, dxp):
+                    if s.requires_grad:
+                        s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
+
+    def activation_bytes(self) -> int:
+        tot = 0
+        for e in self.plan:
+            for k in ("Y", "dsrc"):
+                if k in e:
+                    tot += e[k].numel() * e[k].element_size()
+            for b in e.get("dxp", []):
+                tot += b.numel() * b.element_size()
+        for t in self.T.values():
+            if t.buf is not None:
+                tot += t.buf.numel() * t.buf.element_size()
+        return tot

@@ -1,0 +1,331 @@
+"""Network front ends with the reference's names, constructor signatures and state_dict keys
+(reference pytorch_networks_convae.py; ConvAE from .ipynb_checkpoints/pycold-checkpoint.py:989-1115),
+executed by the HIP engine on MI355X.
+
+Only the modules on the training hot path are provided (FluidLayer, Unet, ConvAE) plus the
+small field helpers the reference exports from this module.  Everything numeric inside
+forward()/backward() runs in libmantle_hip kernels; there is no CPU path.
+"""
+import math
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import _lib as L
+from .engine import convae_graph, single_layer_graph, unet_graph
+from .hipnet import HipNetMixin
+from .symmetric_layers_torch import SymmetricConv2d
+
+_SUPPORTED_ACTS = ("gelu", "relu", "silu", "tanh", "selu", "elu")
+
+
+class color:
+    PURPLE = "\033[95m"
+    CYAN = "\033[96m"
+    DARKCYAN = "\033[36m"
+    BLUE = "\033[94m"
+    GREEN = "\033[92m"
+    YELLOW = "\033[93m"
+    RED = "\033[91m"
+    BOLD = "\033[1m"
+    UNDERLINE = "\033[4m"
+    END = "\033[0m"
+
+
+# --------------------------------------------------------------------------------------------------
+# field helpers (API surface of the reference module; host-side/data-preparation use, device-agnostic)
+# --------------------------------------------------------------------------------------------------
+def _dx(v, w):      # 1x3 / 1x4 cross-correlation, 'valid'
+    n = len(w)
+    W = v.shape[-1]
+    return sum(w[i] * v[..., i:W - n + 1 + i] for i in range(n) if w[i] != 0)
+
+
+def _dy(v, w):
+    n = len(w)
+    H = v.shape[-2]
+    return sum(w[i] * v[..., i:H - n + 1 + i, :] for i in range(n) if w[i] != 0)
+
+
+def dx_right(v, device=None): return _dx(v, (0, -1, 1))          # reference :183-190
+def dy_bot(v, device=None): return _dy(v, (0, -1, 1))            # :193-199
+def dx_left(v, device=None): return _dx(v, (-1, 1, 0))           # :202-208
+def dy_top(v, device=None): return _dy(v, (-1, 1, 0))            # :211-215
+def dx_center(v, device=None): return _dx(v, (-0.5, 0, 0.5))     # :218-224
+def dy_center(v, device=None): return _dy(v, (-0.5, 0, 0.5))     # :227-233
+def du_dy(v, device=None): return _dy(v, (1, -1, -1, 1))         # :236-242
+def dv_dx(v, device=None): return _dx(v, (1, -1, -1, 1))         # :245-251
+
+
+def laplace(v, device=None):                                      # :254-260 (5-point)
+    return (v[..., :-2, 1:-1] + v[..., 2:, 1:-1] + v[..., 1:-1, :-2] + v[..., 1:-1, 2:] - 4 * v[..., 1:-1, 1:-1])
+
+
+def get_mass(u, v, bc=False):
+    """Centred-difference divergence on the interior (reference :27-52; H, W taken from the input
+    instead of the hard-coded 128 x 506)."""
+    H, W = u.shape[-2:]
+    u = u.reshape(-1, 1, H, W)
+    v = v.reshape(-1, 1, H, W)
+    du_dx = dx_center(u)[..., 1:-1, :].clone()
+    dv_dy = dy_center(v)[..., :, 1:-1].clone()
+    if bc:
+        du_dx[:, :, :, 0] *= 2.0 / 1.5
+        du_dx[:, :, :, -1] *= 2.0 / 1.5
+        dv_dy[:, :, 0, :] *= 2.0 / 1.5
+        dv_dy[:, :, -1, :] *= 2.0 / 1.5
+    return du_dx + dv_dy
+
+
+def pad_grad(x, p=(1, 1, 1, 1)):
+    """Linear-extrapolation padding: p = (left, right, last-row side, first-row side) (reference :55-83)."""
+    for _ in range(p[0]):
+        x = torch.cat((2 * x[:, :, :, 0:1] - x[:, :, :, 1:2], x), dim=-1)
+    for _ in range(p[1]):
+        x = torch.cat((x, 2 * x[:, :, :, -1:] - x[:, :, :, -2:-1]), dim=-1)
+    for _ in range(p[2]):
+        x = torch.cat((x, 2 * x[:, :, -1:, :] - x[:, :, -2:-1, :]), dim=-2)
+    for _ in range(p[3]):
+        x = torch.cat((2 * x[:, :, 0:1, :] - x[:, :, 1:2, :], x), dim=-2)
+    return x
+
+
+def eta_torch(gamma, beta, z, T, Tref=0, zref=0):
+    """Frank-Kamenetskii viscosity exp(ln(gamma)(Tref-T) + ln(beta)(z-zref)) (reference :86-102)."""
+    return torch.exp(torch.log(gamma) * (Tref - T) + torch.log(beta) * (z - zref))
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def exists(val):
+    return val is not None
+
+
+def get_lr(optimizer):
+    for param_group in optimizer.param_groups:
+        return param_group["lr"]
+
+
+def pad_uvp(u, v, p=None):
+    """Wall padding of (u, v, p): replicate along the wall, antisymmetric normal velocity, zero
+    corners (reference :145-178)."""
+    def zero_corners(t):
+        t[:, :, 0, 0] = 0.0
+        t[:, :, 0, -1] = 0.0
+        t[:, :, -1, 0] = 0.0
+        t[:, :, -1, -1] = 0.0
+        return t
+    u = torch.cat((u[:, :, 0:1], u, u[:, :, -1:]), dim=2)
+    u = zero_corners(torch.cat((-u[:, :, :, 0:1], u, -u[:, :, :, -1:]), dim=3))
+    v = torch.cat((v[:, :, :, 0:1], v, v[:, :, :, -1:]), dim=3)
+    v = zero_corners(torch.cat((-v[:, :, 0:1, :], v, -v[:, :, -1:, :]), dim=2))
+    if p is not None:
+        p = torch.cat((p[:, :, 0:1], p, p[:, :, -1:]), dim=2)
+        p = zero_corners(torch.cat((p[:, :, :, 0:1], p, p[:, :, :, -1:]), dim=3))
+    return u, v, p
+
+
+# --------------------------------------------------------------------------------------------------
+# FluidLayer (reference :702-799): conv -> GroupNorm -> activation -> dropout(p)
+# --------------------------------------------------------------------------------------------------
+def _check_common(act_fn, r_p, dilation, drop_rate=0.0, spectral_conv=False, blurr=False):
+    if act_fn not in _SUPPORTED_ACTS:
+        raise NotImplementedError(f"act_fn={act_fn!r}: supported on the HIP path: {_SUPPORTED_ACTS} "
+                                  "('sine' is undefined in the reference itself)")
+    if r_p not in ("zeros", "replicate", "reflect"):
+        raise NotImplementedError(f"r_p={r_p!r}: the HIP path implements zeros / replicate / reflect padding "
+                                  "('learned' padding is a different operator, out of scope)")
+    if dilation != 1:
+        raise NotImplementedError("dilation != 1 is not implemented on the HIP path")
+    if drop_rate not in (0, 0.0):
+        raise NotImplementedError("dropout with p > 0 is not implemented on the HIP path (reference default 0)")
+    if spectral_conv:
+        raise NotImplementedError("spectral_conv is out of scope (FFT path)")
+    if blurr:
+        raise NotImplementedError("blurr is out of scope")
+
+
+class FluidLayer(nn.Module, HipNetMixin):
+    def __init__(self, c_i: int, c_o: int, act_fn: str = "selu", r_p="zeros", use_symm=False, dilation=1, f=3,
+                 drop_rate=0.0):
+        super().__init__()
+        _check_common(act_fn, r_p, dilation, drop_rate)
+        self.r_p = "constant" if r_p == "zeros" else r_p
+        self.act_fn = act_fn
+        self.layers = nn.ModuleList()
+        h_s = int(c_o / 4) if c_o > 4 else int(c_o / 2)
+        if use_symm:
+            self.layers.append(SymmetricConv2d(c_i, c_o, kernel_size=f, padding="same", dilation=dilation,
+                                               padding_mode=r_p, symmetry={"h": h_s, "v": 0, "hv": 0}))
+        else:
+            self.layers.append(nn.Conv2d(c_i, c_o, kernel_size=f, padding="same", dilation=dilation,
+                                         padding_mode=r_p))
+        self.layers.append(torch.nn.GroupNorm(int(c_o / min(4, c_o)), c_o))
+        self._init_hipnet(single_layer_graph(c_i, c_o, f, f // 2, r_p, h_s if use_symm else 0, L.POST_GN_ACT,
+                                             act_fn, int(c_o / min(4, c_o)), gn=True))
+
+    def forward(self, inputs, bc_x=1, bc_y=1):
+        return self._run_graph(inputs)
+
+
+# --------------------------------------------------------------------------------------------------
+# curl head (Unet :2038-2070) as an autograd function over the HIP kernels
+# --------------------------------------------------------------------------------------------------
+class _CurlHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, a_bound):
+        """y: [N, C, H, W] f32 network output; channel 0 = streamfunction, channel 1 = T."""
+        N, Cc, H, W = y.shape
+        y = y.contiguous()
+        u = torch.empty((N, H, W), dtype=torch.float32, device=y.device)
+        v = torch.empty_like(u)
+        Tc = torch.empty_like(u)
+        L.call("mc_curl_head_fwd", L.ptr(y), y.data_ptr() + 4 * H * W, N, H, W, Cc * H * W, float(a_bound), 0.0, 1.5,
+               L.ptr(u), L.ptr(v), L.ptr(Tc), L.stream())
+        ctx.save_for_backward(y)
+        ctx.a_bound = float(a_bound)
+        return u, v, Tc
+
+    @staticmethod
+    def backward(ctx, gu, gv, gT):
+        (y,) = ctx.saved_tensors
+        N, Cc, H, W = y.shape
+        gy = torch.zeros_like(y)
+        ws = torch.empty(2 * N * (H - 2) * (W - 2), dtype=torch.float32, device=y.device)
+        gu = (gu if gu is not None else torch.zeros((N, H, W), device=y.device)).contiguous().float()
+        gv = (gv if gv is not None else torch.zeros((N, H, W), device=y.device)).contiguous().float()
+        gT = (gT if gT is not None else torch.zeros((N, H, W), device=y.device)).contiguous().float()
+        L.call("mc_curl_head_bwd", L.ptr(gu), L.ptr(gv), L.ptr(gT), y.data_ptr() + 4 * H * W, N, H, W, ctx.a_bound,
+               0.0, 1.5, L.ptr(gy), gy.data_ptr() + 4 * H * W, Cc * H * W, Cc * H * W, L.ptr(ws), L.stream())
+        return gy, None
+
+
+# --------------------------------------------------------------------------------------------------
+# Unet (reference :1700-2070)
+# --------------------------------------------------------------------------------------------------
+class Unet(nn.Module, HipNetMixin):
+    """Symmetric-convolution U-Net for the Stokes surrogate.  Same constructor, parameters and
+    state_dict keys as the reference; forward returns (u, v, p, T)."""
+
+    def __init__(self, levels: int, c_i: int, c_h: int, c_o: int, device=torch.device("cpu"), act_fn: str = "gelu",
+                 r_p="replicate", loss_type="curl", use_symm=False, dilation=1, a_bound=10.0, use_cosine=False,
+                 repeats=2, use_skip=False, f=5, p_pred=False, spectral_conv=False, blurr=False, drop_rate=0.0):
+        super().__init__()
+        _check_common(act_fn, r_p, dilation, drop_rate, spectral_conv, blurr)
+        self.levels, self.loss_type, self.a_bound = levels, loss_type, a_bound
+        self.use_cosine, self.repeats, self.use_skip, self.p_pred = use_cosine, repeats, use_skip, p_pred
+        self.blurrer = None
+        self.r_p = "constant" if r_p == "zeros" else r_p
+        self.act_fn = act_fn
+        graph = unet_graph(levels, c_i, c_h, c_o, act=act_fn, r_p=r_p, use_symm=use_symm, repeats=repeats, f=f)
+
+        def fl(cin, cout):
+            return FluidLayer(cin, cout, act_fn, r_p, use_symm, dilation, f=f, drop_rate=drop_rate)
+
+        # module tree in the reference's construction order (:1842-1983) so state_dict keys match
+        self.conv = nn.ModuleList()
+        self.gn = nn.ModuleList()
+        for r in range(repeats):
+            self.conv.append(fl(c_i if r == 0 else c_h, c_h))
+        self.pool = nn.AvgPool2d((2, 2), stride=2)
+        self.convs = nn.ModuleList()
+        c = c_h
+        for l in range(1, levels):
+            self.convs.append(nn.ModuleList())
+            for r in range(repeats):
+                self.convs[-1].append(fl(int(c / 2) if (r == 0 and l > 1) else c, c))
+            c *= 2
+        c = int(c / 2)
+        self.upconvs = nn.ModuleList()
+        for l in range(levels - 2, 0, -1):
+            self.upconvs.append(nn.ModuleList())
+            for r in range(repeats):
+                self.upconvs[-1].append(fl(c + int(c / 2) if r == 0 else int(c / 2), int(c / 2)))
+            c = int(c / 2)
+        self.conv.append(nn.Conv2d(int(c * 2), c, kernel_size=f, padding="same", dilation=dilation, padding_mode=r_p))
+        self.gn.append(torch.nn.GroupNorm(int(c / 4), c))
+        self.conv.append(nn.Conv2d(c, c, kernel_size=f, padding="same", padding_mode=r_p))
+        self.conv.append(nn.Conv2d(c, c_o, kernel_size=f, padding="same", padding_mode=r_p))
+        self._init_hipnet(graph)
+
+    def features(self, inputs):
+        """(y - mean_HW(y))[..., 3:-3] — everything up to the output heads (:1985-2024)."""
+        return self._run_graph(inputs)
+
+    def forward(self, inputs):
+        y = self.features(inputs)
+        if self.loss_type in ("mae", "mass"):
+            u, v, T = y[:, 0:1], y[:, 1:2], y[:, 2:3]
+            p = y[:, 3:4] if self.p_pred else None
+            return u, v, p, T
+        elif self.loss_type == "curl":
+            u, v, T = _CurlHead.apply(y, self.a_bound)
+            p = y[:, 2] if self.p_pred else None
+            return u, v, p, T
+        raise ValueError(self.loss_type)
+
+
+# --------------------------------------------------------------------------------------------------
+# ConvAE (reference .ipynb_checkpoints/pycold-checkpoint.py:989-1115)
+# --------------------------------------------------------------------------------------------------
+class ConvAE(nn.Module, HipNetMixin):
+    def __init__(self, levels: int, c_i: int, c_h: int, c_o: int, device=None, act_fn: str = "selu", r_p="zeros",
+                 loss_type="mae", use_symm=False, dilation=1, a_bound=4.0, use_cosine=False, repeats=3,
+                 use_skip=False, f=3, p_pred=True, spectral_conv=False, blurr=False):
+        super().__init__()
+        _check_common(act_fn, r_p, dilation, 0.0, spectral_conv, blurr)
+        self.levels, self.loss_type, self.a_bound = levels, loss_type, a_bound
+        self.use_cosine, self.repeats, self.use_skip, self.p_pred = use_cosine, repeats, use_skip, p_pred
+        self.blurrer = None
+        self.r_p = "constant" if r_p == "zeros" else r_p
+        graph = convae_graph(levels, c_i, c_h, c_o, act=act_fn, r_p=r_p, use_symm=use_symm, repeats=repeats, f=f,
+                             loss_type=loss_type)
+        factor = 4
+
+        def fl(cin, cout):
+            return FluidLayer(int(cin), int(cout), act_fn, r_p, use_symm, dilation, f=f)
+
+        self.conv = nn.ModuleList()
+        self.gn = nn.ModuleList()
+        self.pool = nn.ModuleList()
+        self.unpool = nn.ModuleList()
+        self.conv.append(fl(c_i, c_h))
+        c = c_h
+        for _ in range(levels):
+            self.conv.append(nn.AvgPool2d((factor, factor), stride=factor))
+            cout = c * factor
+            for r in range(repeats):
+                self.conv.append(fl(c if r == 0 else cout, cout))
+            c *= factor
+        c = int(c / factor)
+        for r in range(repeats):
+            self.conv.append(fl(c * factor if r == 0 else c, c))
+        for _ in range(levels, 0, -1):
+            self.conv.append(torch.nn.Upsample(scale_factor=factor, mode="bicubic"))
+            cout = c / factor
+            for r in range(repeats):
+                self.conv.append(fl(c if r == 0 else cout, cout))
+            c = int(c / factor)
+        padding = (2, 2) if loss_type == "curl" else (1, 1)
+        self.conv.append(nn.Conv2d(int(c), int(c_o), kernel_size=3, padding=padding, dilation=1, padding_mode=r_p))
+        self._init_hipnet(graph)
+
+    def forward(self, x):
+        x = self._run_graph(x)
+        if self.loss_type == "curl":
+            # streamfunction head on the (H+2)x(W+2) output of the padding-2 final conv (:1099-1113);
+            # pure slicing/differences on the small output tensor
+            a = x[:, -1:] * self.a_bound
+            u = dy_center(a)[..., :, 1:-1]
+            v = -dx_center(a)[..., 1:-1, :]
+            if self.p_pred:
+                x = torch.cat((x[:, :-2, 1:-1, 1:-1], u, v, x[:, -2:-1, 1:-1, 1:-1]), dim=1)
+            else:
+                x = torch.cat((x[:, :-1, 1:-1, 1:-1], u, v), dim=1)
+        return x
