@@ -80,8 +80,11 @@ const char* mc_strerror(int code);
 /* ---- boundary layout conversion ---------------------------------------------------------- */
 /* NCHW f32 -> CB8 with optional W padding (Unet.forward's F.pad(inputs,(3,3,0,0),mode=r_p),
  * pytorch_networks_convae.py:1991).  out is [n][ceil(c/8)][h][w + 2 pad_w][8]. */
-int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t pad_w,
-                 int32_t pad_mode, int32_t dtype, void* out, void* stream);
+/* x holds src_c >= c channels per sample (only the first c are taken: get_loss feeds the net the
+ * first ten of gVTp's channels, multigpu.py:234-248); chan_scale (nullable, [c]) multiplies each
+ * channel on the way in (xc/4, yc/4, dt/roll_forward). */
+int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
+                 int32_t pad_mode, const float* chan_scale, int32_t dtype, void* out, void* stream);
 /* CB8 -> NCHW f32, optionally subtracting a per-(n,c) mean and cropping crop_w columns on
  * both sides ((y - mean(y))[..., 3:-3], pytorch_networks_convae.py:2024).  mean may be NULL. */
 int mc_unpack_nchw(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w,
@@ -187,17 +190,18 @@ typedef struct {
 int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w, float* mm, void* stream);
 /* Fused forward + backward of the data / derivative / divergence terms.  u,v,p,T: predictions
  * [n][h][w] f32 with the given batch strides (p may be NULL); sums: MC_LOSS_SLOTS doubles
- * (zeroed by the caller); gu..gT: d(loss)/d(pred), same strides as the predictions
- * (overwritten).  The momentum term is added by mc_momentum_* below. */
+ * (zeroed by the caller); gu..gT: d(loss)/d(pred), same strides as the predictions (p and gp
+ * use p_batch_stride: in curl mode p is a channel of the network output while u, v, T come
+ * from the curl head) (overwritten).  The momentum term is added by mc_momentum_* below. */
 int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
-                    int64_t pred_batch_stride, const float* uvp, const float* mm, double* sums,
-                    float* gu, float* gv, float* gp, float* gT, void* stream);
+                    int64_t pred_batch_stride, int64_t p_batch_stride, const float* uvp, const float* mm,
+                    double* sums, float* gu, float* gv, float* gp, float* gT, void* stream);
 /* Stokes momentum residual (build-defined).  yc [h][w], paras [n][3] =
  * (RaQ, FKT, FKP), scaler [n].  sx, sy: workspaces [n][h][w] f32. */
 int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, const float* p,
-                         const float* T, int64_t pred_batch_stride, const float* yc, const float* paras,
+                         const float* T, int64_t pred_batch_stride, int64_t p_batch_stride, const float* yc, const float* paras,
                          const float* scaler, double* sums, float* sx, float* sy, void* stream);
-int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pred_batch_stride, const float* yc,
+int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pred_batch_stride, int64_t p_batch_stride, const float* yc,
                         const float* paras, const float* scaler, const float* sx, const float* sy,
                         float* gu, float* gv, float* gp, float* gT, void* stream);
 /* loss6 (+momentum) from the sums, exactly as get_loss combines them: out[8] f32 =

@@ -43,7 +43,7 @@ _CD, _GS, _LD = C.POINTER(ConvDesc), C.POINTER(GradSrc), C.POINTER(LossDesc)
 SIGNATURES = {
     "mc_version": (C.c_int, []),
     "mc_strerror": (C.c_char_p, [C.c_int]),
-    "mc_pack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_pack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_unpack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
@@ -71,9 +71,9 @@ SIGNATURES = {
     "mc_curl_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _i64, _i64,
                                    _vp, _vp]),
     "mc_loss_minmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "mc_loss_fwd_bwd": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mc_momentum_residual": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mc_momentum_adjoint": (C.c_int, [_LD, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_loss_fwd_bwd": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_momentum_residual": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_momentum_adjoint": (C.c_int, [_LD, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_loss_finalize": (C.c_int, [_LD, _vp, _vp, _vp]),
     "mc_adam_step_flat": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
 }

@@ -9,8 +9,8 @@ namespace {
 // NCHW f32 <-> CB8
 // =================================================================================================
 template <typename T>
-__global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int H, int W, int pad_w, int mode,
-                            T* __restrict__ out) {
+__global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int SC, int H, int W, int pad_w, int mode,
+                            const float* __restrict__ cs, T* __restrict__ out) {
   const int Wp = W + 2 * pad_w, C8 = (C + 7) / 8;
   size_t total = (size_t)N * C8 * H * Wp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -24,7 +24,7 @@ __global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int H, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int c = cb * 8 + j;
-      v[j] = (c < C && xs >= 0) ? x[(((size_t)n * C + c) * H + y) * W + xs] : 0.f;
+      v[j] = (c < C && xs >= 0) ? x[(((size_t)n * SC + c) * H + y) * W + xs] * (cs ? cs[c] : 1.f) : 0.f;
     }
     V8<T>::st(out + i * 8, v);
   }
@@ -516,14 +516,14 @@ inline dim3 grid3(int per_plane, int c8, int n, int block = 256, int capx = 64) 
 // ====================================================================================================
 extern "C" {
 
-int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t pad_w, int32_t pad_mode,
-                 int32_t dtype, void* out, void* stream) {
-  if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || pad_w < 0) return MC_EINVAL;
+int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
+                 int32_t pad_mode, const float* chan_scale, int32_t dtype, void* out, void* stream) {
+  if (!x || !out || n <= 0 || c <= 0 || src_c < c || h <= 0 || w <= 0 || pad_w < 0) return MC_EINVAL;
   if (pad_mode == MC_PAD_REFLECT && pad_w >= w) return MC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   size_t total = (size_t)n * ((c + 7) / 8) * h * (w + 2 * pad_w);
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_nchw<float>, grid1(total), dim3(256), 0, s, x, n, c, h, w, pad_w, pad_mode, (float*)out);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, x, n, c, h, w, pad_w, pad_mode, (bf16_t*)out);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_nchw<float>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (bf16_t*)out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;

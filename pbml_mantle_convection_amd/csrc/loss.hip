@@ -31,7 +31,8 @@ __global__ void k_minmax(const float* __restrict__ uvp, int ct, int hw, float* _
 struct LossGeom {
   mc_loss_desc d;
   int ct;           // channels of uvp
-  int64_t pbs;      // batch stride of the prediction planes
+  int64_t pbs;      // batch stride of the u, v, T prediction planes
+  int64_t ppbs;     // batch stride of the p plane
 };
 
 // weight(y,x) * sign(D(y,x)) of the divergence term, 0 outside the interior
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
   const int H = g.d.h, W = g.d.w, HW = H * W, n = blockIdx.y;
   const float* u = u_ + (size_t)n * g.pbs;
   const float* v = v_ + (size_t)n * g.pbs;
-  const float* p = p_ ? p_ + (size_t)n * g.pbs : nullptr;
+  const float* p = p_ ? p_ + (size_t)n * g.ppbs : nullptr;
   const float* T = T_ + (size_t)n * g.pbs;
   const float* ut = uvp + ((size_t)n * g.ct + 0) * HW;
   const float* vt = uvp + ((size_t)n * g.ct + 1) * HW;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
     }
     gu_[(size_t)n * g.pbs + i] = gu;
     gv_[(size_t)n * g.pbs + i] = gv;
-    if (gp_) gp_[(size_t)n * g.pbs + i] = gp;
+    if (gp_) gp_[(size_t)n * g.ppbs + i] = gp;
     if (gT_) gT_[(size_t)n * g.pbs + i] = g.d.t_grad ? gT : 0.f;
   }
   block_add(a_us, sums + MC_S_U_SCALED); block_add(a_up, sums + MC_S_U_PLAIN);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
 // ------------------------------------------------------------------------------------------------
 struct MomGeom {
   int N, H, W;
-  int64_t pbs;
+  int64_t pbs, ppbs;
   float ih, ra, lam;
 };
 
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
   const int H = g.H, W = g.W, HW = H * W, n = blockIdx.y;
   const float* u = u_ + (size_t)n * g.pbs;
   const float* v = v_ + (size_t)n * g.pbs;
-  const float* p = p_ ? p_ + (size_t)n * g.pbs : nullptr;
+  const float* p = p_ ? p_ + (size_t)n * g.ppbs : nullptr;
   const float* T = T_ + (size_t)n * g.pbs;
   MomField f{T, yc, logf(paras[n * 3 + 1]), logf(paras[n * 3 + 2]), H, W};
   const float s = scaler[n], ih = g.ih;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
     float dP = -0.5f * ih * (SX(i, j - 1) - SX(i, j + 1)) - 0.5f * ih * (SY(i - 1, j) - SY(i + 1, j));
     gu_[(size_t)n * g.pbs + idx] += s * dU;
     gv_[(size_t)n * g.pbs + idx] += s * dV;
-    if (gp_) gp_[(size_t)n * g.pbs + idx] += dP;
+    if (gp_) gp_[(size_t)n * g.ppbs + idx] += dP;
     if (gT_ && t_grad) gT_[(size_t)n * g.pbs + idx] += g.ra * SY(i, j);
   }
 }
@@ -294,15 +295,15 @@ int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w
 }
 
 int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
-                    int64_t pbs, const float* uvp, const float* mm, double* sums, float* gu, float* gv, float* gp,
-                    float* gT, void* stream) {
+                    int64_t pbs, int64_t ppbs, const float* uvp, const float* mm, double* sums, float* gu, float* gv,
+                    float* gp, float* gT, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
   if (!u || !v || !T || !uvp || !sums || !gu || !gv || !gT) return MC_EINVAL;
   if (d->p_pred && (!p || !gp)) return MC_EINVAL;
   if (d->loss_scale && !mm) return MC_EINVAL;
   LossGeom g;
-  g.d = *d; g.ct = d->p_pred ? 4 : 3; g.pbs = pbs;
+  g.d = *d; g.ct = d->p_pred ? 4 : 3; g.pbs = pbs; g.ppbs = ppbs;
   dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
   hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
                      gu, gv, d->p_pred ? gp : nullptr, gT);
@@ -311,25 +312,25 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
 }
 
 int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
-                         int64_t pbs, const float* yc, const float* paras, const float* scaler, double* sums,
-                         float* sx, float* sy, void* stream) {
+                         int64_t pbs, int64_t ppbs, const float* yc, const float* paras, const float* scaler,
+                         double* sums, float* sx, float* sy, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
   if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy) return MC_EINVAL;
-  MomGeom g{d->n, d->h, d->w, pbs, d->inv_h, d->ra, d->lambda_mom};
+  MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
   dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
   hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, yc, paras, scaler, sums, sx, sy);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
 
-int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, const float* yc, const float* paras,
+int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, int64_t ppbs, const float* yc, const float* paras,
                         const float* scaler, const float* sx, const float* sy, float* gu, float* gv, float* gp,
                         float* gT, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
   if (!T || !yc || !paras || !scaler || !sx || !sy || !gu || !gv) return MC_EINVAL;
-  MomGeom g{d->n, d->h, d->w, pbs, d->inv_h, d->ra, d->lambda_mom};
+  MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
   dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
   hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, T, yc, paras, scaler, sx, sy, gu, gv, gp, gT,
                      d->t_grad);

@@ -1,0 +1,314 @@
+"""Datasets of the Stokes-surrogate trainer with the reference's item layouts (reference
+datasetio.py) plus the seeded synthetic generator used where the /plp_scr1 data files are
+absent.
+
+  ADTimeDataset.__getitem__  -> (x[10,H,W], y[3,H,W], scaler, paras[3,1,1], yc[1,H,W])   (:229-280)
+  NewADDataset.__getitem__   -> (x[7,H,W], y[2|3,H,W], t_weight, scaler)                 (:595-654)
+
+File loading uses torch.load(weights_only=True): nothing from a data file is executed.
+"""
+import copy   # noqa: F401  (names the reference exports through its star imports)
+import os
+import random
+import time   # noqa: F401
+
+import numpy as np
+import torch
+import torch.nn as nn   # noqa: F401
+import torch.nn.functional as F   # noqa: F401
+from torch.utils.data import DataLoader, Dataset   # noqa: F401
+
+from .pytorch_networks_convae import eta_torch
+from .scaler import *   # noqa: F401,F403
+from .scaler import velocity_scaler
+
+# normalisation constants of (RaQ, log10 FKT, log10 FKP) (reference :124-136)
+RAQ_RANGE = (0.12624371, 9.70723344)
+LOG_FKT_RANGE = (6.00352841978384, 9.888820429862925)
+LOG_FKP_RANGE = (0.005251646002323797, 1.9927988938926755)
+IGNORED_SIMS = (8, 39)
+
+
+def _load(path):
+    return torch.load(path, weights_only=True)
+
+
+def get_sdf(x, y):
+    """Distance to the nearest wall of the box (reference :13-22)."""
+    dx = torch.minimum(torch.abs(x - x.min()), torch.abs(x - x.max()))
+    dy = torch.minimum(torch.abs(y - y.min()), torch.abs(y - y.max()))
+    return torch.minimum(dx, dy)
+
+
+def eta(gamma, beta, z, T, Tref=0, zref=0):
+    return np.exp(np.log(gamma) * (Tref - T) + np.log(beta) * (z - zref))
+
+
+def normalise_parameters(raq, fkt, fkp):
+    return ((raq - RAQ_RANGE[0]) / (RAQ_RANGE[1] - RAQ_RANGE[0]),
+            (np.log10(fkt) - LOG_FKT_RANGE[0]) / (LOG_FKT_RANGE[1] - LOG_FKT_RANGE[0]),
+            (np.log10(fkp) - LOG_FKP_RANGE[0]) / (LOG_FKP_RANGE[1] - LOG_FKP_RANGE[0]))
+
+
+def _selected_sims(data_dir, an):
+    for si, sim in enumerate(_load(data_dir + "/sims.pt")):
+        if sim[1] == an and si not in IGNORED_SIMS:
+            yield sim, data_dir + "/" + sim[1] + "/sim_" + str(sim[0])
+
+
+def get_indices_time(data_dir, an, is_init=False, debug=True, roll_forward=1):
+    """(simulation id, time) pairs that have a successor roll_forward steps ahead (reference :30-60)."""
+    sims_vec, times_vec = [], []
+    for sim, d in _selected_sims(data_dir, "train" if an == "train" else "cv"):
+        if debug:
+            n = _load(d + "/e1_uprev_data_select_init.pt").repeat(roll_forward * 2, 1, 1, 1).shape[0]
+            times = _load(d + "/times.pt")[:n]
+        else:
+            times = _load(d + "/times.pt")[:750, ...][:-2]
+        for i, t in enumerate(times):
+            if i < len(times) - roll_forward - 1:
+                sims_vec.append(sim[0])
+                times_vec.append(t)
+    return sims_vec, times_vec
+
+
+def get_indices(data_dir, an, is_init=False, debug=True, roll_forward=1):
+    """(simulation id, snapshot index) pairs of the sub-sampled snapshot files (reference :283-317)."""
+    sims_vec, times_vec = [], []
+    for sim, d in _selected_sims(data_dir, "train" if an == "train" else "cv"):
+        if is_init:
+            i_vec = _load(d + "/e1_i_vec_select_init.pt")
+        elif debug:
+            i_vec = np.arange(_load(d + "/e1_uprev_data_select_snaps.pt").shape[0])
+        else:
+            i_vec = _load(d + "/e1_i_vec_select.pt")
+        for i_prev in i_vec:
+            sims_vec.append(sim[0])
+            times_vec.append(i_prev)
+    return sims_vec, times_vec
+
+
+class _GridMixin:
+    def _load_grid(self, d):
+        xc, yc = _load(d + "/xc.pt"), _load(d + "/yc.pt")
+        self.xc = xc.view(1, *xc.shape).clone()
+        self.yc = yc.view(1, *yc.shape).clone()
+        self.xc[:, :, 0], self.xc[:, :, -1] = 0, 4          # wall nodes (reference :158-161, 401-404)
+        self.yc[:, 0, :], self.yc[:, -1, :] = 0, 1
+
+
+class ADTimeDataset(Dataset, _GridMixin):
+    """Consecutive-snapshot pairs for the U-Net (reference :63-280)."""
+
+    def __init__(self, data_dir, an, scale=True, load=False, is_init=False, p_pred=True, noise=0.0, debug=True,
+                 sims_vec=[], times_vec=[], roll_forward=1):
+        self.y_data, self.x_data, self.t_data, self.t = [], [], [], []
+        self.paras, self.paras_nd, self.indices, self.indices_init = [], [], [], []
+        self.scale, self.p_pred, self.noise = scale, p_pred, noise
+        cntr = 0
+        tv, sv = np.asarray(times_vec), np.asarray(sims_vec)
+        for si, sim in enumerate(_load(data_dir + "/sims.pt")):
+            _, _, raq, fkt, fkp, _, _, _ = sim
+            d = data_dir + "/" + sim[1] + "/sim_" + str(sim[0])
+            wanted = (sim[1] == an) and (len(sims_vec) == 0 or sim[0] in sims_vec)
+            times = _load(d + "/times.pt")
+            if not (wanted and si not in IGNORED_SIMS and len(times) > 1):
+                continue
+            nd = normalise_parameters(raq, fkt, fkp)
+            self._load_grid(d)
+            paras = torch.tensor([raq, fkt, fkp], dtype=torch.float64).view(3, 1, 1)
+            paras_nd = torch.tensor(nd, dtype=torch.float64).view(3, 1, 1)
+            if debug:
+                if p_pred:
+                    raise ValueError("p_pred is not implemented in debug mode")
+                reps = max(1, int(roll_forward / 2 * 2))
+                u, v, Tp = (_load(d + f"/e1_{k}prev_data_select_init.pt").repeat(reps, 1, 1, 1) for k in "uvT")
+            else:
+                u, v, Tp = (_load(d + f"/e1_{k}prev_data.pt")[:760, ...] for k in "uvT")
+                if p_pred:
+                    p = _load(d + "/e1_pprev_data.pt")[:760, ...]
+            times = times[: u.shape[0]]
+            mine = tv[sv == sim[0]] if len(sims_vec) > 0 else None
+            for i, t in enumerate(times):
+                keep = True if mine is None else (t in mine)
+                if keep and i < len(times) - roll_forward - 1:
+                    self.indices.append([cntr, cntr + roll_forward])
+                    if i == 0:
+                        self.indices_init.append([cntr, cntr + roll_forward])
+                cntr += 1
+                self.paras.append(paras)
+                self.paras_nd.append(paras_nd)
+                self.x_data.append(Tp[i, ...])
+                self.y_data.append(torch.cat((u[i], v[i], p[i]) if p_pred else (u[i], v[i]), axis=0))
+                self.t_data.append(torch.tensor(t, dtype=torch.float64))
+                self.t.append(t)
+        self.num_examples = len(self.indices)
+
+    def __len__(self):
+        return self.num_examples
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        i0, i1 = self.indices[idx]
+        if i0 % 8 == 0:
+            i0, i1 = random.choice(self.indices_init)
+        par = self.paras[i0]
+        assert torch.all(par == self.paras[i1])
+        scaler = velocity_scaler(par[0:1], par[1:2], par[2:3])
+        Tp, y = self.x_data[i0].double(), self.y_data[i0].double()
+        V = eta_torch(par[1:2], par[2:3], 1.0 - self.yc, Tp)
+        shape = (1, Tp.shape[-2], Tp.shape[-1])
+        nd = self.paras_nd[i0]
+        x = torch.cat((self.xc, self.yc,
+                       torch.tensor(self.t[i1] - self.t[i0], dtype=torch.float64).expand(shape),
+                       nd[0:1].expand(shape), nd[1:2].expand(shape), nd[2:3].expand(shape),
+                       torch.log10(torch.clip(V, 1e-8, 1.0)) / 8.0, Tp, y[0:1] / scaler, y[1:2] / scaler), axis=0)
+        y1 = self.y_data[i1].double()
+        y_new = torch.cat((y1[0:1] / scaler, y1[1:2] / scaler, self.x_data[i1].double()), axis=0)
+        return x, y_new, scaler, par, self.yc
+
+
+class NewADDataset(Dataset, _GridMixin):
+    """Sub-sampled snapshots T -> (u, v[, p]) for the FluidNet family (reference :320-654)."""
+
+    def __init__(self, data_dir, an, scale=True, load=False, is_init=False, p_pred=True, noise=0.0, debug=True,
+                 sims_vec=[], times_vec=[], max_examples_percent_per_epoch=100):
+        self.y_data, self.x_data, self.t_data, self.paras, self.paras_nd = [], [], [], [], []
+        self.scale, self.p_pred, self.noise = scale, p_pred, noise
+        suffix = "_select_init" if is_init else ("_select_snaps" if debug else "_select")
+        for si, sim in enumerate(_load(data_dir + "/sims.pt")):
+            _, _, raq, fkt, fkp, _, _, _ = sim
+            d = data_dir + "/" + sim[1] + "/sim_" + str(sim[0])
+            wanted = (sim[1] == an) and (len(sims_vec) == 0 or sim[0] in sims_vec)
+            times = _load(d + "/times.pt")
+            if not (wanted and si not in IGNORED_SIMS and len(times) > 1):
+                continue
+            self._load_grid(d)
+            paras = torch.tensor([raq, fkt, fkp], dtype=torch.float64).view(3, 1, 1)
+            paras_nd = torch.tensor(normalise_parameters(raq, fkt, fkp), dtype=torch.float64).view(3, 1, 1)
+            u, v, Tp = (_load(d + f"/e1_{k}prev_data{suffix}.pt") for k in "uvT")
+            p = _load(d + f"/e1_pprev_data{suffix}.pt") if p_pred else None
+            for i in range(u.shape[0]):
+                self.paras.append(paras)
+                self.paras_nd.append(paras_nd)
+                self.x_data.append(Tp[i])
+                self.y_data.append(torch.cat((u[i], v[i], p[i]) if p_pred else (u[i], v[i]), axis=0))
+                self.t_data.append(torch.tensor(float(times[min(i, len(times) - 1)]), dtype=torch.float64))
+        self.num_examples = int(len(self.y_data) * max_examples_percent_per_epoch / 100)
+        print("using ", self.num_examples, " out of ", len(self.y_data), " per epoch")
+
+    def __len__(self):
+        return self.num_examples
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        par, nd = self.paras[idx], self.paras_nd[idx]
+        Tp = self.x_data[idx].double().clone()
+        if self.noise > 0:
+            n = torch.tensor(np.random.uniform(-1e-5, 1e-5, size=(1, Tp.shape[-2] - 4, Tp.shape[-1] - 4)))
+            Tp[:, 2:-2, 2:-2] = torch.clip(Tp[:, 2:-2, 2:-2] + n, 0.0, 1.35)
+        y = self.y_data[idx].double()
+        V = torch.clip(eta_torch(par[1:2], par[2:3], 1.0 - self.yc, Tp), 1e-08, 1)
+        if not self.scale:
+            raise NotImplementedError("scale=False returns nothing in the reference either")
+        scaler = velocity_scaler(par[0:1], par[1:2], par[2:3])
+        shape = (1, Tp.shape[-2], Tp.shape[-1])
+        x = torch.cat((self.xc / 4, self.yc / 4, torch.log10(V) / 8, nd[0:1].expand(shape), nd[1:2].expand(shape),
+                       nd[2:3].expand(shape), Tp), axis=0)
+        parts = (y[0:1] / scaler, y[1:2] / scaler) + ((y[2:3],) if self.p_pred else ())
+        return x, torch.cat(parts, axis=0), self.t_data[idx].double(), scaler
+
+
+# --------------------------------------------------------------------------------------------------
+# synthetic mantle fields: same item layout as ADTimeDataset, no files needed
+# --------------------------------------------------------------------------------------------------
+def synthetic_batch(B, H, W, seed, *, p_pred=True, device="cpu", dtype=torch.float32, channels=None):
+    """Seeded synthetic (gVTp, uvp, scaler, paras, yc) with the statistics of the real data:
+    T = conductive profile + Gaussian plumes; parameters from the dataset's ranges; previous and
+    target velocities from random streamfunctions (divergence-free targets); p low-pass random."""
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    y1 = torch.linspace(0, 1, H, dtype=torch.float64)
+    x1 = torch.linspace(0, 4, W, dtype=torch.float64)
+    yy, xx = y1[:, None].expand(H, W), x1[None, :].expand(H, W)
+
+    def U(lo, hi, *shape):
+        return lo + (hi - lo) * torch.rand(*shape, generator=g, dtype=torch.float64)
+
+    def stream_uv():
+        psi_y = torch.zeros(B, H, W, dtype=torch.float64)
+        psi_x = torch.zeros(B, H, W, dtype=torch.float64)
+        for _ in range(8):
+            a, kx, ky = U(-1, 1, B, 1, 1), U(0.5, 6, B, 1, 1), U(1, 8, B, 1, 1)
+            px, py = U(0, 6.28, B, 1, 1), U(0, 6.28, B, 1, 1)
+            psi_y = psi_y + a * ky * torch.sin(kx * xx + px) * torch.cos(ky * yy + py)    # d psi / dy
+            psi_x = psi_x + a * kx * torch.cos(kx * xx + px) * torch.sin(ky * yy + py)    # d psi / dx
+        s = 0.1 / psi_y.abs().mean().clamp_min(1e-9)
+        return s * psi_y, -s * psi_x
+
+    def smooth(amp):
+        f = torch.zeros(B, H, W, dtype=torch.float64)
+        for _ in range(6):
+            f = f + U(-1, 1, B, 1, 1) * torch.sin(U(0.5, 5, B, 1, 1) * xx + U(0, 6.28, B, 1, 1)) * \
+                torch.cos(U(0.5, 6, B, 1, 1) * yy + U(0, 6.28, B, 1, 1))
+        return amp * f / 3.0
+
+    def temperature():
+        T = (1.0 - yy).expand(B, H, W).clone()
+        for _ in range(4):
+            a, s = U(0.05, 0.3, B, 1, 1), U(0.03, 0.15, B, 1, 1)
+            cx, cy = U(0, 4, B, 1, 1), U(0, 1, B, 1, 1)
+            T = T + a * torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        T = torch.clip(T + 1e-3 * torch.randn(B, H, W, generator=g, dtype=torch.float64), 0.0, 1.35)
+        T[:, 0, :], T[:, -1, :] = 1.0, 0.0
+        T[:, :, 0], T[:, :, -1] = T[:, :, 1], T[:, :, -2]
+        return T
+
+    raq = U(RAQ_RANGE[0], RAQ_RANGE[1], B)
+    fkt = 10.0 ** U(LOG_FKT_RANGE[0], LOG_FKT_RANGE[1], B)
+    fkp = 10.0 ** U(LOG_FKP_RANGE[0], LOG_FKP_RANGE[1], B)
+    nd = [t.view(B, 1, 1).expand(B, H, W) for t in normalise_parameters(raq, fkt, fkp)]
+    T0, T1 = temperature(), temperature()
+    u0, v0 = stream_uv()
+    u1, v1 = stream_uv()
+    p0, p1 = smooth(0.5), smooth(0.5)
+    V = torch.log10(torch.clip(eta_torch(fkt.view(B, 1, 1), fkp.view(B, 1, 1), 1.0 - yy, T0), 1e-8, 1.0)) / 8.0
+    dt = U(1e-7, 1e-4, B).view(B, 1, 1).expand(B, H, W)
+    chans = [xx.expand(B, H, W), yy.expand(B, H, W), dt, nd[0], nd[1], nd[2], V, T0, u0, v0]
+    if p_pred:
+        chans.append(p0)
+    gVTp = torch.stack(chans, 1)
+    if channels is not None:
+        gVTp = gVTp[:, :channels]
+    uvp = torch.stack([u1, v1, p1, T1] if p_pred else [u1, v1, T1], 1)
+    scaler = torch.as_tensor(velocity_scaler(raq.numpy(), fkt.numpy(), fkp.numpy()))
+    paras = torch.stack([raq, fkt, fkp], 1)
+    to = dict(device=device, dtype=dtype)
+    return gVTp.to(**to), uvp.to(**to), scaler.to(**to), paras.to(**to), yy.contiguous().to(**to)
+
+
+class SyntheticMantleDataset(Dataset):
+    """ADTimeDataset-shaped items from `synthetic_batch` (generated once, kept in host RAM)."""
+
+    def __init__(self, n, H, W, p_pred=True, seed=1234, network="unet", c_i=None):
+        chunk = 8
+        parts = [synthetic_batch(min(chunk, n - i), H, W, seed + i, p_pred=p_pred) for i in range(0, n, chunk)]
+        self.x = torch.cat([p[0] for p in parts])
+        self.y = torch.cat([p[1] for p in parts])
+        self.scaler = torch.cat([p[2] for p in parts])
+        self.paras = torch.cat([p[3] for p in parts])
+        self.yc = parts[0][4]
+        self.network = network
+        if network == "convae":
+            # ConvAE plumbing config (CFG-1): T (+ two parameter maps) -> (u, v, p)
+            self.x = torch.stack([self.x[:, 7], self.x[:, 3], self.x[:, 4]], 1) if (c_i or 3) == 3 else self.x[:, :c_i]
+            self.y = self.y[:, :3]
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        if self.network == "convae":
+            return self.x[i], self.y[i], torch.tensor(0.0), self.scaler[i]
+        return self.x[i], self.y[i], self.scaler[i], self.paras[i].view(3, 1, 1), self.yc.view(1, *self.yc.shape)

@@ -367,20 +367,22 @@ class Engine:
         return self._tables[key]
 
     # -------------------------------------------------------------- forward
-    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """x: [N, c_in, H, W] f32 device tensor -> [N, c_out, H', W'] f32."""
+    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], chan_scale=None) -> torch.Tensor:
+        """x: [N, >= c_in, H, W] f32 device tensor (extra trailing channels are ignored)
+        -> [N, c_out, H', W'] f32.  chan_scale: optional [c_in] f32 per-channel input scale."""
         L.require_cuda(x, "network input")
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
         N, Ci, H, W = x.shape
-        if Ci != self.g.c_in:
-            raise ValueError(f"expected {self.g.c_in} input channels, got {Ci}")
+        if Ci < self.g.c_in:
+            raise ValueError(f"expected at least {self.g.c_in} input channels, got {Ci}")
         self.configure(N, H, W, x.device)
         st = L.stream()
         g, T = self.g, self.T
         act = L.ACTS[g.act]
-        L.call("mc_pack_nchw", L.ptr(x), N, Ci, H, W, g.in_pad_w, self.mode, self.mc_dtype, L.ptr(T[0].buf), st)
+        L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
+               L.ptr(T[0].buf), st)
         for e in self.plan:
             node = e["node"]
             if node.kind == "up":

@@ -21,7 +21,7 @@ class _NetFunction(torch.autograd.Function):
     def forward(ctx, mod, x, *plist):
         eng = mod.engine()
         params = mod._param_dict(plist)
-        out = eng.forward(x, params)
+        out = eng.forward(x, params, getattr(mod, "_chan_scale", None))
         mod._fwd_version += 1
         ctx.mod, ctx.params, ctx.version = mod, params, mod._fwd_version
         ctx.dtypes = [p.dtype for p in plist]
@@ -120,9 +120,16 @@ class FlatParams:
                 p.data = view
                 p.grad = self.grad[off:off + p.numel()].view(shp)
 
+        self._views = {}
+
     def views(self, flat):
-        return {n: flat[off:off + int(torch.Size(s).numel())].view(s)
-                for n, off, s in zip(self.names, self.offsets, self.shapes)}
+        """name -> view of `flat` (cached per buffer)."""
+        key = flat.data_ptr()
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = {n: flat[off:off + int(torch.Size(s).numel())].view(s)
+                                    for n, off, s in zip(self.names, self.offsets, self.shapes)}
+        return v
 
     def bound(self) -> bool:
         """True while the module's parameters are still views of the flat buffer."""

@@ -1,0 +1,134 @@
+"""Fused training loss on MI355X: Trainer.loss_fn / get_loss arithmetic (reference
+multigpu.py:122-134, 250-305) plus the build-defined Stokes momentum residual, forward AND
+backward in one pass over the fields (libmantle_hip: mc_loss_* / mc_momentum_* / mc_curl_head_*).
+
+`StokesLoss.evaluate` works on raw device buffers (used by the fused trainer, graph-capturable);
+`StokesLoss.__call__` is the autograd-visible form used by Trainer.get_loss.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+OUT_NAMES = ("loss", "loss_true_u", "loss_true_v", "loss_p", "loss_T", "mass", "momentum", "_")
+
+
+class StokesLoss:
+    def __init__(self, p_pred: bool, loss_type: str, loss_scale: bool = False, loss_derivative: bool = False,
+                 norm: str = "l1", lambda_mom: float = 0.0, inv_h: float = 126.0, ra: float = 1.0,
+                 a_bound: float = 10.0, t_grad: bool = True):
+        if loss_type not in L.LOSS_TYPES:
+            raise ValueError(f"loss_type must be one of {list(L.LOSS_TYPES)}")
+        if norm not in ("l1", "l2"):
+            raise ValueError("norm must be 'l1' (reference) or 'l2'")
+        self.p_pred, self.loss_type = bool(p_pred), loss_type
+        self.loss_scale, self.loss_derivative = bool(loss_scale), bool(loss_derivative)
+        self.norm, self.lambda_mom, self.inv_h, self.ra = norm, float(lambda_mom), float(inv_h), float(ra)
+        self.a_bound, self.t_grad = float(a_bound), bool(t_grad)
+        self._shape = None
+
+    # ------------------------------------------------------------------
+    def _alloc(self, N, Cc, H, W, dev):
+        if self._shape == (N, Cc, H, W, str(dev)):
+            return
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(L.LOSS_SLOTS, dtype=torch.float64, device=dev)
+        self.out8 = torch.zeros(8, **f32)
+        self.mm = torch.zeros((N, 2, 2), **f32)
+        self.gy = torch.zeros((N, Cc, H, W), **f32)
+        if self.loss_type == "curl":
+            self.cu, self.cv, self.cT = (torch.empty((N, H, W), **f32) for _ in range(3))
+            self.gcu, self.gcv, self.gcT = (torch.empty((N, H, W), **f32) for _ in range(3))
+            self.curl_ws = torch.empty(2 * N * (H - 2) * (W - 2), **f32)
+        if self.lambda_mom != 0.0:
+            self.sx = torch.empty((N, H, W), **f32)
+            self.sy = torch.empty((N, H, W), **f32)
+        self._shape = (N, Cc, H, W, str(dev))
+
+    def channels_needed(self):
+        if self.loss_type == "curl":
+            return 3 if self.p_pred else 2
+        return 4 if self.p_pred else 3
+
+    def evaluate(self, y: torch.Tensor, uvp: torch.Tensor, yc: Optional[torch.Tensor] = None,
+                 paras: Optional[torch.Tensor] = None, scaler: Optional[torch.Tensor] = None):
+        """y: network output [N, C, H, W] f32 (Unet.features / ConvAE output); uvp: truth
+        [N, 3|4, H, W] f32.  Returns (out8, gy): out8 = (loss, true_u, true_v, loss_p, loss_T, mass,
+        momentum, 0) on device; gy = d(loss)/d(y)."""
+        L.require_cuda(y, "network output")
+        L.require_cuda(uvp, "uvp")
+        if y.dtype != torch.float32 or not y.is_contiguous():
+            raise RuntimeError("y must be contiguous f32")
+        if uvp.dtype != torch.float32 or not uvp.is_contiguous():
+            uvp = uvp.float().contiguous()
+        N, Cc, H, W = y.shape
+        if Cc < self.channels_needed():
+            raise ValueError(f"network output has {Cc} channels, loss needs {self.channels_needed()}")
+        ct = 4 if self.p_pred else 3
+        if tuple(uvp.shape) != (N, ct, H, W):
+            raise ValueError(f"uvp must be [{N},{ct},{H},{W}], got {tuple(uvp.shape)}")
+        self._alloc(N, Cc, H, W, y.device)
+        st = L.stream()
+        HW = H * W
+        d = L.LossDesc(N, H, W, int(self.p_pred), L.LOSS_TYPES[self.loss_type], int(self.loss_scale),
+                       int(self.loss_derivative), int(self.norm == "l2"), self.lambda_mom, self.inv_h, self.ra,
+                       int(self.t_grad))
+        self.sums.zero_()
+        if self.loss_scale:
+            L.call("mc_loss_minmax", L.ptr(uvp), N, ct, H, W, L.ptr(self.mm), st)
+        yb, gb = y.data_ptr(), self.gy.data_ptr()
+        if self.loss_type == "curl":
+            # channel 0 = streamfunction, 1 = T, 2 = p  (reference pytorch_networks_convae.py:2038-2049)
+            self.gy.zero_()
+            L.call("mc_curl_head_fwd", yb, yb + 4 * HW, N, H, W, Cc * HW, self.a_bound, 0.0, 1.5, L.ptr(self.cu),
+                   L.ptr(self.cv), L.ptr(self.cT), st)
+            u, v, T, pbs = self.cu.data_ptr(), self.cv.data_ptr(), self.cT.data_ptr(), HW
+            gu, gv, gT = self.gcu.data_ptr(), self.gcv.data_ptr(), self.gcT.data_ptr()
+            p = yb + 4 * 2 * HW if self.p_pred else None
+            gp = gb + 4 * 2 * HW if self.p_pred else None
+        else:
+            # channels u, v, T, p  (:2026-2036)
+            u, v, T, pbs = yb, yb + 4 * HW, yb + 4 * 2 * HW, Cc * HW
+            gu, gv, gT = gb, gb + 4 * HW, gb + 4 * 2 * HW
+            p = yb + 4 * 3 * HW if self.p_pred else None
+            gp = gb + 4 * 3 * HW if self.p_pred else None
+            if Cc > ct:
+                self.gy.zero_()
+        ppbs = Cc * HW
+        L.call("mc_loss_fwd_bwd", C.byref(d), u, v, p, T, pbs, ppbs, L.ptr(uvp), L.ptr(self.mm), L.ptr(self.sums), gu,
+               gv, gp, gT, st)
+        if self.lambda_mom != 0.0:
+            if yc is None or paras is None or scaler is None:
+                raise ValueError("the momentum term needs yc [H,W], paras [N,3] and scaler [N]")
+            yc = yc.reshape(-1, H, W)[0].float().contiguous()
+            paras = paras.reshape(N, 3).float().contiguous()
+            scaler = scaler.reshape(N).float().contiguous()
+            L.call("mc_momentum_residual", C.byref(d), u, v, p, T, pbs, ppbs, L.ptr(yc), L.ptr(paras), L.ptr(scaler),
+                   L.ptr(self.sums), L.ptr(self.sx), L.ptr(self.sy), st)
+            L.call("mc_momentum_adjoint", C.byref(d), T, pbs, ppbs, L.ptr(yc), L.ptr(paras), L.ptr(scaler),
+                   L.ptr(self.sx), L.ptr(self.sy), gu, gv, gp, gT, st)
+        if self.loss_type == "curl":
+            L.call("mc_curl_head_bwd", gu, gv, gT, yb + 4 * HW, N, H, W, self.a_bound, 0.0, 1.5, gb, gb + 4 * HW,
+                   Cc * HW, Cc * HW, L.ptr(self.curl_ws), st)
+        L.call("mc_loss_finalize", C.byref(d), L.ptr(self.sums), L.ptr(self.out8), st)
+        return self.out8, self.gy
+
+    def __call__(self, y, uvp, yc=None, paras=None, scaler=None):
+        """Autograd-visible: returns out8 whose element 0 back-propagates d(loss)/dy into y."""
+        return _LossFn.apply(self, y, uvp, yc, paras, scaler)
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss_obj, y, uvp, yc, paras, scaler):
+        out8, gy = loss_obj.evaluate(y.contiguous(), uvp, yc, paras, scaler)
+        ctx.gy = gy.clone()
+        return out8.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        return None, ctx.gy * gout[0], None, None, None, None

@@ -1,0 +1,196 @@
+"""GPU parity of the fused training step: loss kernels (forward + backward) against the CPU
+oracle's autograd, the momentum residual, fused Adam, and two full training steps against the
+golden vectors captured from the reference (zero_grad -> get_loss -> backward -> Adam)."""
+import numpy as np
+import pytest
+import torch
+
+import fields
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+f64 = torch.float64
+
+
+def dev(a):
+    return torch.from_numpy(np.asarray(a)).float().to(DEV).contiguous()
+
+
+def close(a, b, atol, rtol, what=""):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    assert (err <= atol + rtol * np.abs(b)).all(), f"{what}: max err {err.max():.3e}, ref max {np.abs(b).max():.3e}"
+
+
+def _case(B, H, W, seed, p_pred):
+    u = fields.smooth_field(B, H, W, seed + 1, noise=0.01)
+    v = fields.smooth_field(B, H, W, seed + 2, noise=0.01)
+    p = fields.smooth_field(B, H, W, seed + 3, amp=0.5)
+    T = fields.temperature_field(B, H, W, seed + 4)
+    truth = [fields.smooth_field(B, H, W, seed + 5), fields.smooth_field(B, H, W, seed + 6)]
+    if p_pred:
+        truth.append(fields.smooth_field(B, H, W, seed + 7, amp=0.5))
+    truth.append(fields.temperature_field(B, H, W, seed + 8))
+    return u, v, p, T, np.stack(truth, 1)
+
+
+@pytest.mark.parametrize("p_pred", [True, False])
+@pytest.mark.parametrize("loss_type", ["mae", "mass"])
+@pytest.mark.parametrize("ls,ld,norm", [(False, False, "l1"), (True, True, "l1"), (True, False, "l2")])
+def test_fused_loss_matches_oracle(p_pred, loss_type, ls, ld, norm):
+    from pbml_mantle_convection_amd.losses import StokesLoss
+    B, H, W = 2, 37, 53
+    u, v, p, T, uvp = _case(B, H, W, 100, p_pred)
+    chans = [u, v, T] + ([p] if p_pred else [])
+    y = dev(np.stack(chans, 1))
+    L = StokesLoss(p_pred, loss_type, ls, ld, norm=norm)
+    out8, gy = L.evaluate(y, dev(uvp))
+    tu, tv, tp, tT = (torch.from_numpy(a).to(f64).requires_grad_(True) for a in (u, v, p, T))
+    ref = O.get_loss_unet((tu, tv, tp if p_pred else None, tT), torch.from_numpy(uvp).to(f64), p_pred=p_pred,
+                          loss_type=loss_type, loss_scale=ls, loss_derivative=ld, norm=norm)
+    close(out8[:6], torch.stack([r.detach() for r in ref]), atol=1e-6, rtol=2e-5, what="loss6")
+    ref[0].backward()
+    gref = [tu.grad, tv.grad, tT.grad] + ([tp.grad] if p_pred else [])
+    for i, gr in enumerate(gref):
+        close(gy[:, i], gr, atol=1e-9, rtol=1e-4, what=f"grad ch{i}")
+
+
+@pytest.mark.parametrize("p_pred", [True, False])
+def test_fused_loss_curl_matches_oracle(p_pred):
+    """curl mode: streamfunction -> (u, v) with wall conditions, T clip, boundary-strip divergence."""
+    from pbml_mantle_convection_amd.losses import StokesLoss
+    B, H, W = 2, 23, 31
+    a, _, p, T, uvp = _case(B, H, W, 200, p_pred)
+    T = T * 1.3 - 0.1            # exercise both clip sides
+    y_np = np.stack([a, T] + ([p] if p_pred else []), 1)
+    y = dev(y_np)
+    L = StokesLoss(p_pred, "curl", True, True, a_bound=10.0)
+    out8, gy = L.evaluate(y, dev(uvp))
+    ty = torch.from_numpy(y_np).to(f64).requires_grad_(True)
+    cu, cv = O.curl_head(ty[:, 0:1] * 10.0)
+    pred = (cu[:, 0], cv[:, 0], ty[:, 2] if p_pred else None, torch.clip(ty[:, 1], 0.0, 1.5))
+    ref = O.get_loss_unet(pred, torch.from_numpy(uvp).to(f64), p_pred=p_pred, loss_type="curl", loss_scale=True,
+                          loss_derivative=True)
+    close(out8[:6], torch.stack([r.detach() for r in ref]), atol=1e-6, rtol=2e-5, what="loss6")
+    ref[0].backward()
+    close(gy, ty.grad, atol=1e-8, rtol=2e-4, what="gy")
+
+
+def test_momentum_residual_matches_oracle():
+    from pbml_mantle_convection_amd.losses import StokesLoss
+    B, H, W = 2, 29, 41
+    u, v, p, T, uvp = _case(B, H, W, 300, True)
+    paras = fields.sim_parameters(B, 5)
+    paras[:, 1] = 10.0 ** np.array([2.0, 3.0])      # moderate viscosity contrast keeps the f32 sign pattern stable
+    scaler = np.array([30.0, 80.0])
+    yc = np.broadcast_to(np.linspace(0, 1, H)[:, None], (H, W)).copy()
+    y = dev(np.stack([u, v, T, p], 1))
+    lam = 1e-6
+    L = StokesLoss(True, "mass", False, False, lambda_mom=lam)
+    out8, gy = L.evaluate(y, dev(uvp), dev(yc), dev(paras), dev(scaler))
+    tu, tv, tp, tT = (torch.from_numpy(a).to(f64).requires_grad_(True) for a in (u, v, p, T))
+    mom = dict(lambda_mom=lam, yc=torch.from_numpy(yc), paras=torch.from_numpy(paras), scaler=torch.from_numpy(scaler))
+    ref = O.get_loss_unet((tu, tv, tp, tT), torch.from_numpy(uvp).to(f64), p_pred=True, loss_type="mass", momentum=mom)
+    close(out8[6], ref[6].detach(), atol=0, rtol=2e-4, what="momentum value")
+    close(out8[0], ref[0].detach(), atol=1e-6, rtol=2e-4, what="loss")
+    ref[0].backward()
+    for i, gr in enumerate([tu.grad, tv.grad, tT.grad, tp.grad]):
+        g = gy[:, i].double().cpu()
+        # sign(R) can flip where |R| is at rounding level; require agreement on >= 99.5 % of the pixels
+        bad = (g - gr).abs() > 1e-7 + 2e-3 * gr.abs()
+        assert bad.double().mean() < 5e-3, (i, float(bad.double().mean()))
+
+
+def test_fused_adam_matches_torch():
+    from pbml_mantle_convection_amd import _lib as L
+    n = 10007
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=2e-3, weight_decay=1e-2)
+    npad = (n + 3) // 4 * 4
+    p = torch.zeros(npad, device=DEV); p[:n] = p0.to(DEV)
+    m = torch.zeros(npad, device=DEV); v = torch.zeros(npad, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lr = torch.full((1,), 2e-3, device=DEV)
+    for it in range(5):
+        gr = torch.randn(n, generator=g)
+        ref_p.grad = gr.clone()
+        opt.step()
+        gd = torch.zeros(npad, device=DEV); gd[:n] = (gr * 4.0).to(DEV)       # grad_scale 1/4 undoes the x4
+        L.call("mc_adam_step_flat", L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), n, L.ptr(lr), 0.9, 0.999, 1e-8, 1e-2, 0.25,
+               L.ptr(step), L.stream())
+    close(p[:n], ref_p.detach(), atol=1e-6, rtol=1e-5, what="adam params")
+    assert int(step.item()) == 5
+
+
+@pytest.mark.parametrize("tag", ["mass", "curl"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_training_steps_golden(golden, tag, use_graph):
+    """The whole fused step on the GPU vs the reference's two steps (f32 mode)."""
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    g = golden(f"g11_train_{tag}")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm, ls, ld = [int(v) for v in g["cfg"]]
+    B, H, W = 2, 128, 506
+    m = Unet(levels, c_i, c_h, c_o, torch.device(DEV), "gelu", "reflect", str(g["loss_type"]), use_symm=bool(symm),
+             repeats=repeats, f=f, p_pred=bool(p_pred))
+    m.load_state_dict({k[4:]: torch.from_numpy(g[k]).float() for k in g.files if k.startswith("sd0/")})
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=bool(p_pred), network="unet",
+                 loss_scale=bool(ls), loss_derivative=bool(ld), loss_type=str(g["loss_type"]), precision="fp32",
+                 use_graph=use_graph)
+    for step in range(2):
+        gVTp = dev(fields.unet_input(B, H, W, 1100 + step, c_i=11 if p_pred else 10))
+        truth = [fields.smooth_field(B, H, W, 1150 + step), fields.smooth_field(B, H, W, 1160 + step)]
+        if p_pred:
+            truth.append(fields.smooth_field(B, H, W, 1170 + step, amp=0.5))
+        truth.append(fields.temperature_field(B, H, W, 1180 + step))
+        uvp = dev(np.stack(truth, 1))
+        if step == 0 and not use_graph:
+            out8 = tr._fwd_bwd(gVTp, uvp, None, None, None, train=True)
+            for n, gr in tr.flat.views(tr.flat.grad).items():
+                ref = g["grad0/" + n]
+                close(gr, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
+            tr._sync_lr()
+            tr._optim_step()
+            vals = out8[:6].tolist()
+        else:
+            vals = tr._run_batch(gVTp, uvp, None, True)
+        close(np.array(vals), g["losses"][step], atol=1e-6, rtol=5e-5, what=f"losses step {step}")
+    for n, p in m.named_parameters():
+        if float(np.abs(g["grad0/" + n]).max()) < 1e-9:
+            # null direction (the last conv's bias is cancelled by the spatial mean subtraction): its gradient is
+            # pure rounding noise, which Adam normalises to +-lr whatever its size -> not comparable
+            continue
+        close(p, g["sd2/" + n], atol=2e-5, rtol=1e-4, what="param " + n)
+
+
+def test_get_loss_autograd_path(golden):
+    """Reference-style usage: loss6 = trainer.get_loss(...); loss.backward(); torch optimizer step."""
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    g = golden("g11_train_mass")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm, ls, ld = [int(v) for v in g["cfg"]]
+    B, H, W = 2, 128, 506
+    m = Unet(levels, c_i, c_h, c_o, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=repeats, f=f,
+             p_pred=True)
+    m.load_state_dict({k[4:]: torch.from_numpy(g[k]).float() for k in g.files if k.startswith("sd0/")})
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet",
+                 loss_type="mass", precision="fp32")
+    gVTp = dev(fields.unet_input(B, H, W, 1100, c_i=11))
+    truth = [fields.smooth_field(B, H, W, 1150), fields.smooth_field(B, H, W, 1160),
+             fields.smooth_field(B, H, W, 1170, amp=0.5), fields.temperature_field(B, H, W, 1180)]
+    for p in m.parameters():
+        p.grad = None
+    loss6 = tr.get_loss(gVTp, dev(np.stack(truth, 1)), None)
+    close(torch.stack([v.detach() for v in loss6]), g["losses"][0], atol=1e-6, rtol=5e-5, what="loss6")
+    loss6[0].backward()
+    for n, p in m.named_parameters():
+        ref = g["grad0/" + n]
+        close(p.grad, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
