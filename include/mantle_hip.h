@@ -105,6 +105,9 @@ size_t mc_packed_weight_bytes(const mc_conv_desc* d, int32_t dgrad);
  * the transposed, 180-degree-rotated bank used by mc_conv2d for the input gradient. */
 int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad, void* packed,
                     void* stream);
+/* Symbol-style name of the kernel instantiation mc_conv2d launches for this descriptor (static string;
+ * lets a profiler trace be matched to a descriptor). */
+const char* mc_conv_kernel_name(const mc_conv_desc* d);
 /* Number of spatial tiles per image the conv kernel uses for this descriptor (sizes stat partials). */
 int32_t mc_conv_tiles(const mc_conv_desc* d);
 /* y = conv(pad(cat(x0,x1))) + bias.  y0 (and y1 when c_out_split) are CB8 outputs.

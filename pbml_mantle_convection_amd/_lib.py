@@ -50,6 +50,7 @@ SIGNATURES = {
     "mc_packed_weight_bytes": (_sz, [_CD, _i32]),
     "mc_pack_weights": (C.c_int, [_CD, _vp, _i32, _vp, _vp]),
     "mc_conv_tiles": (_i32, [_CD]),
+    "mc_conv_kernel_name": (C.c_char_p, [_CD]),
     "mc_conv2d": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_wgrad_partial_bytes": (_sz, [_CD]),
     "mc_conv2d_wgrad": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp]),
@@ -79,7 +80,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is a quantity, not a status code
-VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_packed_weight_bytes", "mc_conv_tiles",
+VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_conv_kernel_name", "mc_packed_weight_bytes", "mc_conv_tiles",
                    "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks"}
 
 _lib = None

@@ -11,6 +11,7 @@ int mc_bf16_pack(const ConvGeom& g, const float* w_unique, int dgrad, void* pack
 int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
                    void* y1, float* part, hipStream_t s);
 int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s);
+const char* mc_bf16_kernel_name(const ConvGeom& g);
 
 namespace {
 
@@ -143,6 +144,13 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
   hipLaunchKernelGGL(k_pack_f32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, w_unique, dgrad, (float*)packed);
   MC_CHECK_LAUNCH();
   return MC_OK;
+}
+
+const char* mc_conv_kernel_name(const mc_conv_desc* d) {
+  ConvGeom g;
+  if (geom_for(d, g)) return "unsupported";
+  if (g.dtype == MC_BF16) return mc_bf16_kernel_name(g);
+  return g.K == 5 ? "k_conv_direct_f32<5>" : "k_conv_direct_f32<3>";
 }
 
 int32_t mc_conv_tiles(const mc_conv_desc* d) {

@@ -6,3 +6,4 @@ size_t mc_bf16_bank_bytes(const ConvGeom& g, int dgrad) { (void)g; (void)dgrad; 
 int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hipStream_t s) { (void)g; (void)w; (void)dgrad; (void)packed; (void)s; return MC_EUNSUPPORTED; }
 int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1, float* part, hipStream_t s) { (void)g; (void)x0; (void)x1; (void)bank; (void)bias; (void)y0; (void)y1; (void)part; (void)s; return MC_EUNSUPPORTED; }
 int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s) { (void)g; (void)x0; (void)x1; (void)dy; (void)part; (void)s; return MC_EUNSUPPORTED; }
+const char* mc_bf16_kernel_name(const ConvGeom& g) { (void)g; return "unsupported"; }

@@ -399,8 +399,10 @@ class Engine:
             o = T[node.out]
             final = node.post == L.POST_NONE
             need_part = node.post == L.POST_GN_ACT or (final and g.subtract_mean)
+            self._probe_begin()
             L.call("mc_conv2d", C.byref(d), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf) if len(srcs) > 1 else None,
                    L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None, L.ptr(e["part"]) if need_part else None, st)
+            self._probe_end(d, "fwd " + node.name)
             if node.post == L.POST_GN_ACT:
                 L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
                        L.ptr(e["stats"]), None, st)
@@ -493,11 +495,72 @@ class Engine:
                 w = self._param(params, node.name + "weight")
                 L.call("mc_pack_weights", C.byref(d), L.ptr(w), 1, L.ptr(e["dbank"]), st)
                 dxp = e["dxp"]
+                self._probe_begin()
                 L.call("mc_conv2d", C.byref(e["ddesc"]), L.ptr(dY), None, L.ptr(e["dbank"]), None, L.ptr(dxp[0]),
                        L.ptr(dxp[1]) if len(dxp) > 1 else None, None, st)
+                self._probe_end(e["ddesc"], "dgrad " + node.name)
                 for s, buf in zip(srcs, dxp):
                     if s.requires_grad:
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
+
+    # -------------------------------------------------------------- measurement hooks (bench.py)
+    _probe = None
+
+    def enable_probe(self):
+        """Record a HIP-event pair (on the launch stream) around every mc_conv2d launch."""
+        self._probe = []
+        return self._probe
+
+    def disable_probe(self):
+        self._probe = None
+
+    def _probe_begin(self):
+        if self._probe is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._probe_ev = ev
+
+    def _probe_end(self, d, label):
+        if self._probe is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            es = torch.tensor([], dtype=self.t_dtype).element_size()
+            ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
+            cin = d.c_in0 + d.c_in1
+            nbytes = d.n * es * (cin * d.h * d.w + d.c_out * ho * wo)          # algorithmic: read input once, write output once
+            flops = 2.0 * d.n * cin * d.c_out * d.k * d.k * ho * wo
+            name = L.load().mc_conv_kernel_name(C.byref(d)).decode()
+            self._probe.append((name, label, self._probe_ev, ev, nbytes, flops))
+
+    @staticmethod
+    def probe_summary(probe, hbm_peak_gbs):
+        """Dominant conv kernel (largest total time): algorithmic bytes per launch / mean launch duration."""
+        groups = {}
+        for name, label, e0, e1, nbytes, flops in probe:
+            g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, flops=0.0, n=0))
+            g["ms"] += e0.elapsed_time(e1)
+            g["bytes"] += nbytes
+            g["flops"] += flops
+            g["n"] += 1
+        name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": ach / hbm_peak_gbs,
+                "traffic": None, "kernel": name, "launches": g["n"], "avg_launch_us": 1e3 * g["ms"] / g["n"],
+                "avg_algorithmic_MB_per_launch": g["bytes"] / g["n"] / 1e6,
+                "tflops": g["flops"] / (g["ms"] * 1e-3) / 1e12,
+                "share_of_conv_time": g["ms"] / sum(v["ms"] for v in groups.values())}
+
+    def algorithmic_bytes_per_sample(self, precision=None) -> float:
+        """3 s (sum_in + sum_out over the conv layers) + s_io (C_i + 2 C_o) H W."""
+        s = 2 if (precision or self.precision) == "bf16" else 4
+        tot = 0
+        for e in self.plan:
+            if e["node"].kind != "conv":
+                continue
+            d = e["desc"]
+            ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
+            tot += (d.c_in0 + d.c_in1) * d.h * d.w + d.c_out * ho * wo
+        return 3.0 * s * tot + 4.0 * (self.g.c_in + 2 * self.g.c_out) * self.out_h * self.out_w
 
     def activation_bytes(self) -> int:
         tot = 0
