@@ -63,6 +63,8 @@ typedef struct {
   int32_t dtype;      /* MC_F32 | MC_BF16 : element type of x0, x1, y                */
   int32_t sym_h;      /* number of x-mirrored filters (SymmetricConv2d symmetry['h']), 0 = plain Conv2d */
   int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
+  int32_t out_f32;    /* dtype == MC_BF16 only: write y0 as f32 CB8 (the network's last conv: u,v,p,T are not
+                         quantised to bf16); requires c_out <= 16 and no split */
 } mc_conv_desc;
 
 typedef struct {

@@ -193,6 +193,67 @@ def unet_features(sd, x, levels, repeats, act, r_p, use_symm) -> Tensor:
     return (y - y.mean(dim=(2, 3), keepdim=True))[..., 3:-3]
 
 
+def unet_features_quantised(sd, x, levels, repeats, act, r_p, use_symm, q) -> Tensor:
+    """unet_features with the storage rounding of the device's bf16 mode emulated: `q` (e.g. a bf16
+    round-trip) is applied wherever the engine stores a tensor — packed input, filter banks, raw conv
+    outputs (GroupNorm statistics are taken BEFORE that rounding, from the f32 accumulators), activated
+    outputs, pooled and upsampled tensors; the last conv's output stays f32.  Forward only (tests)."""
+    mode = torch_pad_mode(r_p)
+
+    def conv(xin, w, b):
+        return conv2d_same(xin, q(w), b, r_p)
+
+    def layer(prefix, xin, gn_prefix=None, post="gn_act"):
+        w = sd[prefix + "weight"]
+        b = sd[prefix + "bias"]
+        c_o = b.shape[0]
+        if use_symm and prefix.endswith("layers.0."):
+            w = expand_symmetric_weight(w, symmetry_counts(c_o))
+        y = conv(xin, w, b)
+        if post == "none":
+            return y, y
+        yq = q(y)
+        if post == "gn_act":
+            G = gn_groups(c_o) if gn_prefix.endswith("layers.1.") else int(c_o / 4)
+            B = y.shape[0]
+            yg = y.reshape(B, G, -1)
+            mean = yg.mean(-1, keepdim=True)
+            var = yg.var(-1, unbiased=False, keepdim=True)
+            z = ((yq.reshape(B, G, -1) - mean) / torch.sqrt(var + 1e-5)).reshape(y.shape)
+            z = z * sd[gn_prefix + "weight"].view(1, -1, 1, 1) + sd[gn_prefix + "bias"].view(1, -1, 1, 1)
+        else:
+            z = yq
+        a = activation(act, z)
+        return q(a), a
+
+    x = F.pad(x, (3, 3, 0, 0)) if mode == "constant" else F.pad(x, (3, 3, 0, 0), mode=mode)
+    cur = q(x)
+    feat, raw = {}, {}
+    for r in range(repeats):
+        cur, un = layer(f"conv.{r}.layers.0.", cur, f"conv.{r}.layers.1.")
+    feat[0], raw[0] = cur, un
+    sizes = {0: cur.shape[-2:]}
+    for l in range(1, levels):
+        cur = q(F.avg_pool2d(raw[l - 1], 2, 2))
+        sizes[l] = cur.shape[-2:]
+        for r in range(repeats):
+            cur, un = layer(f"convs.{l - 1}.{r}.layers.0.", cur, f"convs.{l - 1}.{r}.layers.1.")
+        feat[l], raw[l] = cur, un
+    xu = feat[levels - 1]
+    for li, l in enumerate(range(levels - 2, 0, -1)):
+        xu = q(F.interpolate(xu, size=tuple(sizes[l]), mode="bicubic"))
+        xu = torch.cat((feat[l], xu), dim=1)
+        for r in range(repeats):
+            xu, _ = layer(f"upconvs.{li}.{r}.layers.0.", xu, f"upconvs.{li}.{r}.layers.1.")
+    xu = q(F.interpolate(xu, size=tuple(sizes[0]), mode="bicubic"))
+    y = torch.cat((xu, feat[0]), dim=1)
+    R = repeats
+    y, _ = layer(f"conv.{R}.", y, "gn.0.")
+    y, _ = layer(f"conv.{R + 1}.", y, None, post="act")
+    y, _ = layer(f"conv.{R + 2}.", y, None, post="none")
+    return (y - y.mean(dim=(2, 3), keepdim=True))[..., 3:-3]
+
+
 def curl_head(a: Tensor) -> Tuple[Tensor, Tensor]:
     """Streamfunction a [B,1,H,W] -> (u, v) [B,1,H,W] with antisymmetric wall values and
     zero corners (pytorch_networks_convae.py:2052-2068)."""

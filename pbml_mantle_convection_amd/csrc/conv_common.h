@@ -12,6 +12,7 @@ struct ConvGeom {
   int wgrad_G;              // number of partial slabs of the filter-gradient reduction
   int sym_h, U;             // mirrored filters / unique filters
   int dtype;
+  int out_f32;
 };
 
 // fills g from d; returns MC_OK or an error code.  tile_h/tile_w = output tile of the kernel family.
@@ -39,6 +40,8 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.tiles = g.tiles_x * g.tiles_y;
   g.sym_h = d->sym_h; g.U = d->c_out - d->sym_h / 2;
   g.dtype = d->dtype;
+  g.out_f32 = (d->dtype == MC_BF16) ? d->out_f32 : 0;
+  if (g.out_f32 && (d->c_out > 16 || d->c_out_split != 0)) return MC_EUNSUPPORTED;
   long slab = (long)g.CoutP * ((long)g.CinP * g.K * g.K + 1) * 4;
   long G = (64L << 20) / slab;
   if (G < 32) G = 32;

@@ -304,8 +304,10 @@ class Engine:
             h, w = srcs[0].H, srcs[0].W
             for s in srcs:
                 assert (s.H, s.W) == (h, w), "concat sources must agree in size"
+            final_f32 = (node.post == L.POST_NONE and node is g.nodes[-1] and self.mc_dtype == L.MC_BF16
+                         and node.c_out <= 16)
             d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
-                           mode, self.mc_dtype, node.sym_h, 0)
+                           mode, self.mc_dtype, node.sym_h, 0, int(final_f32))
             ho, wo = h + 2 * node.pad - node.k + 1, w + 2 * node.pad - node.k + 1
             o = T[node.out]
             o.H, o.W = ho, wo
@@ -317,10 +319,11 @@ class Engine:
             cin_tot = sum(s.C for s in srcs)
             # dgrad = the same kernel on the padded domain: zero pad k-1, rotated/transposed bank
             dd = L.ConvDesc(N, ho, wo, node.c_out, 0, cin_tot, node.k, node.k - 1, 0, self.mc_dtype, 0,
-                            srcs[0].C if len(srcs) > 1 else 0)
+                            srcs[0].C if len(srcs) > 1 else 0, 0)
             need_dgrad = any(s.requires_grad for s in srcs)
             e = dict(node=node, desc=d, ddesc=dd, tiles=tiles, coutp=coutp,
-                     Y=cb8(node.c_out, ho, wo),
+                     Y=(torch.empty((N, (node.c_out + 7) // 8, ho, wo, 8), dtype=torch.float32, device=device)
+                        if final_f32 else cb8(node.c_out, ho, wo)),
                      part=torch.empty((N, tiles, coutp, 2), **f32),
                      bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
                      need_dgrad=need_dgrad)
@@ -418,7 +421,8 @@ class Engine:
                        L.ptr(self.chan_mean), st)
         fo = T[self.plan[-1]["node"].out]
         out = torch.empty((N, g.c_out, self.out_h, self.out_w), dtype=torch.float32, device=x.device)
-        L.call("mc_unpack_nchw", L.ptr(fo.buf), N, fo.C, fo.H, fo.W, g.crop_w, L.ptr(self.chan_mean), self.mc_dtype,
+        out_dt = L.MC_F32 if fo.buf.dtype == torch.float32 else self.mc_dtype
+        L.call("mc_unpack_nchw", L.ptr(fo.buf), N, fo.C, fo.H, fo.W, g.crop_w, L.ptr(self.chan_mean), out_dt,
                L.ptr(out), st)
         return out
 

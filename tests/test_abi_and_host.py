@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     import ctypes as C
     from pbml_mantle_convection_amd import _lib
-    assert C.sizeof(_lib.ConvDesc) == 12 * 4
+    assert C.sizeof(_lib.ConvDesc) == 13 * 4
     assert C.sizeof(_lib.GradSrc) == 8 + 6 * 4
     assert C.sizeof(_lib.LossDesc) == 12 * 4
 
@@ -42,12 +42,12 @@ def test_argument_validation_without_gpu():
     import ctypes as C
     from pbml_mantle_convection_amd import _lib as L
     L.load()
-    ok = L.ConvDesc(2, 40, 60, 16, 0, 16, 5, 2, 2, 0, 4, 0)
+    ok = L.ConvDesc(2, 40, 60, 16, 0, 16, 5, 2, 2, 0, 4, 0, 0)
     assert L.call("mc_conv_tiles", C.byref(ok)) == 3 * 4
     assert L.call("mc_packed_weight_bytes", C.byref(ok), 0) == 2 * 25 * 8 * 16 * 4
-    bad_k = L.ConvDesc(2, 40, 60, 16, 0, 16, 4, 2, 2, 0, 4, 0)
+    bad_k = L.ConvDesc(2, 40, 60, 16, 0, 16, 4, 2, 2, 0, 4, 0, 0)
     assert L.call("mc_conv_tiles", C.byref(bad_k)) == -1
-    odd_sym = L.ConvDesc(2, 40, 60, 16, 0, 16, 5, 2, 2, 0, 3, 0)
+    odd_sym = L.ConvDesc(2, 40, 60, 16, 0, 16, 5, 2, 2, 0, 3, 0, 0)
     assert L.call("mc_conv_tiles", C.byref(odd_sym)) == -1
     with pytest.raises(L.MantleHipError):
         L.call("mc_pack_nchw", None, 1, 1, 1, 4, 4, 0, 0, None, 0, None, None)
