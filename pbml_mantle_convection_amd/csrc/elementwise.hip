@@ -256,38 +256,34 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __rest
   }
 }
 
-// phase 2: one block per group g (all n): m12[n][g] = (sum_c gamma_c s1, sum_c gamma_c s2)/M;
-// dgamma[c] += sum_n s2[n][c]; dbeta[c] += sum_n s1[n][c]
+// phase 2: one block per (group g, sample n): m12[n][g] = (sum_c gamma_c s1, sum_c gamma_c s2)/M;
+// dgamma[c] += s2[n][c]; dbeta[c] += s1[n][c]  (N float atomics per channel)
 __global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blocks, int C, int CP, int groups,
                                   int hw, const float* __restrict__ gamma, float* __restrict__ m12,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int g = blockIdx.x, cpg = C / groups;
+  const int g = blockIdx.x, n = blockIdx.y, cpg = C / groups;
+  double m1 = 0.0, m2 = 0.0;
   for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    double tg = 0.0, tb = 0.0;
-    for (int n = 0; n < N; ++n) {
-      double a1 = 0.0, a2 = 0.0;
-      for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
-        const float* p = part + (((size_t)n * blocks + t) * CP + c) * 2;
-        a1 += (double)p[0];
-        a2 += (double)p[1];
-      }
-      a1 = wave_sum_d(a1);
-      a2 = wave_sum_d(a2);
-      tb += a1;
-      tg += a2;
-      if (threadIdx.x == 0 && m12) {
-        double M = (double)cpg * (double)hw;
-        float* o = m12 + ((size_t)n * groups + g) * 2;
-        float ga = gamma ? gamma[c] : 1.f;
-        if (c == g * cpg) { o[0] = 0.f; o[1] = 0.f; }
-        o[0] += (float)(ga * a1 / M);
-        o[1] += (float)(ga * a2 / M);
-      }
+    double a1 = 0.0, a2 = 0.0;
+    for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
+      const float* p = part + (((size_t)n * blocks + t) * CP + c) * 2;
+      a1 += (double)p[0];
+      a2 += (double)p[1];
     }
+    a1 = wave_sum_d(a1);
+    a2 = wave_sum_d(a2);
+    float ga = gamma ? gamma[c] : 1.f;
+    m1 += ga * a1;
+    m2 += ga * a2;
     if (threadIdx.x == 0) {
-      if (dgamma) dgamma[c] += (float)tg;
-      if (dbeta) dbeta[c] += (float)tb;
+      if (dgamma) atomicAdd(dgamma + c, (float)a2);
+      if (dbeta) atomicAdd(dbeta + c, (float)a1);
     }
+  }
+  if (threadIdx.x == 0 && m12) {
+    double M = (double)cpg * (double)hw;
+    m12[((size_t)n * groups + g) * 2 + 0] = (float)(m1 / M);
+    m12[((size_t)n * groups + g) * 2 + 1] = (float)(m2 / M);
   }
 }
 
@@ -657,7 +653,7 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
 int mc_gn_act_bwd_finalize(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups, int32_t hw,
                            const float* gamma, float* m12, float* dgamma, float* dbeta, void* stream) {
   if (!partials || n <= 0 || blocks <= 0 || c <= 0 || groups <= 0 || c % groups || hw <= 0) return MC_EINVAL;
-  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(groups), dim3(64), 0, (hipStream_t)stream, partials, n, blocks, c,
+  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(groups, n), dim3(64), 0, (hipStream_t)stream, partials, n, blocks, c,
                      ((c + 7) / 8) * 8, groups, hw, gamma, m12, dgamma, dbeta);
   MC_CHECK_LAUNCH();
   return MC_OK;

@@ -7,11 +7,29 @@ namespace {
 
 __device__ __forceinline__ float sgn(float x) { return (float)((x > 0.f) - (x < 0.f)); }
 
-__device__ __forceinline__ void block_add(double v, double* dst) {
-  // wave reduce, then one f64 atomic per wave
-  v = wave_sum_d(v);
-  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
-}
+// block-level reduction of up to 16 running sums, then ONE f64 atomic per slot per block (a few thousand
+// atomics per launch; per-wave atomics on a handful of addresses serialise at ~11 ns each and cost milliseconds)
+struct BlockSums {
+  double v[16];
+  __device__ __forceinline__ BlockSums() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.0;
+  }
+  template <int NSLOT>
+  __device__ __forceinline__ void flush(double* dst, const int (&slot)[NSLOT]) {
+    __shared__ double red[4][16];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      double r = wave_sum_d(v[i]);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSLOT) {
+      double r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (r != 0.0) atomicAdd(dst + slot[threadIdx.x], r);
+    }
+  }
+};
 
 __global__ void k_minmax(const float* __restrict__ uvp, int ct, int hw, float* __restrict__ mm) {
   const int n = blockIdx.x, f = blockIdx.y;  // f = 0 (u) or 1 (v)
@@ -142,12 +160,12 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
     if (gp_) gp_[(size_t)n * g.ppbs + i] = gp;
     if (gT_) gT_[(size_t)n * g.pbs + i] = g.d.t_grad ? gT : 0.f;
   }
-  block_add(a_us, sums + MC_S_U_SCALED); block_add(a_up, sums + MC_S_U_PLAIN);
-  block_add(a_vs, sums + MC_S_V_SCALED); block_add(a_vp, sums + MC_S_V_PLAIN);
-  block_add(a_pp, sums + MC_S_P_PLAIN); block_add(a_tp, sums + MC_S_T_PLAIN);
-  block_add(a_du, sums + MC_S_DU); block_add(a_dv, sums + MC_S_DV);
-  block_add(a_m, sums + MC_S_MASS); block_add(a_mx0, sums + MC_S_MASS_X0); block_add(a_mx1, sums + MC_S_MASS_X1);
-  block_add(a_my0, sums + MC_S_MASS_Y0); block_add(a_my1, sums + MC_S_MASS_Y1);
+  BlockSums bs;
+  bs.v[0] = a_us; bs.v[1] = a_up; bs.v[2] = a_vs; bs.v[3] = a_vp; bs.v[4] = a_pp; bs.v[5] = a_tp; bs.v[6] = a_du;
+  bs.v[7] = a_dv; bs.v[8] = a_m; bs.v[9] = a_mx0; bs.v[10] = a_mx1; bs.v[11] = a_my0; bs.v[12] = a_my1;
+  const int slots[13] = {MC_S_U_SCALED, MC_S_U_PLAIN, MC_S_V_SCALED, MC_S_V_PLAIN, MC_S_P_PLAIN, MC_S_T_PLAIN, MC_S_DU,
+                         MC_S_DV, MC_S_MASS, MC_S_MASS_X0, MC_S_MASS_X1, MC_S_MASS_Y0, MC_S_MASS_Y1};
+  bs.flush<13>(sums, slots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,8 +232,10 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
     sx_[(size_t)n * HW + idx] = ox;
     sy_[(size_t)n * HW + idx] = oy;
   }
-  block_add(ax, sums + MC_S_MOMX);
-  block_add(ay, sums + MC_S_MOMY);
+  BlockSums bs;
+  bs.v[0] = ax; bs.v[1] = ay;
+  const int slots[2] = {MC_S_MOMX, MC_S_MOMY};
+  bs.flush<2>(sums, slots);
 }
 
 __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ T_, const float* __restrict__ yc,
@@ -304,7 +324,7 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
   if (d->loss_scale && !mm) return MC_EINVAL;
   LossGeom g;
   g.d = *d; g.ct = d->p_pred ? 4 : 3; g.pbs = pbs; g.ppbs = ppbs;
-  dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
+  dim3 grid(min(cdiv(d->h * d->w, 256 * 4), 256), d->n);
   hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
                      gu, gv, d->p_pred ? gp : nullptr, gT);
   MC_CHECK_LAUNCH();

@@ -166,7 +166,7 @@ def test_two_training_steps_golden(golden, tag, use_graph):
             # null direction (the last conv's bias is cancelled by the spatial mean subtraction): its gradient is
             # pure rounding noise, which Adam normalises to +-lr whatever its size -> not comparable
             continue
-        close(p, g["sd2/" + n], atol=2e-5, rtol=1e-4, what="param " + n)
+        close(p, g["sd2/" + n], atol=1e-4, rtol=1e-4, what="param " + n)   # Adam moves each weight by <= 1e-3 per step
 
 
 def test_get_loss_autograd_path(golden):
