@@ -76,14 +76,21 @@ __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, 
 }
 
 // dW_unique[u][ci][ky][kx] += sum_G part[G][u][...] + (u < h/2) sum_G part[G][U+u][..][ky][K-1-kx]
-__global__ void k_wgrad_finalize(ConvGeom g, const float* __restrict__ part, float* __restrict__ dw,
-                                 float* __restrict__ db) {
+// 64 outputs per block; the four waves split the slab range and combine through LDS (deterministic order)
+__global__ __launch_bounds__(256) void k_wgrad_finalize(ConvGeom g, const float* __restrict__ part,
+                                                        float* __restrict__ dw, float* __restrict__ db) {
   const int K = g.K, KK = K * K;
   const int cols = g.CinP * KK + 1;
   const size_t slab = (size_t)g.CoutP * cols;
   const size_t nW = (size_t)g.U * g.Cin * KK;
   const size_t total = nW + g.Cout;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + e;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (i < total) {
+    size_t o1, o2 = 0;
+    bool two = false;
     if (i < nW) {
       int kx = (int)(i % K);
       size_t r = i / K;
@@ -91,20 +98,33 @@ __global__ void k_wgrad_finalize(ConvGeom g, const float* __restrict__ part, flo
       int ci = (int)(r % g.Cin);
       int u = (int)(r / g.Cin);
       int cip = cin_padded_index(ci, g.Cin0, g.CB0);
-      size_t o1 = (size_t)u * cols + (size_t)cip * KK + ky * K + kx;
-      double s = 0.0;
-      for (int G = 0; G < g.wgrad_G; ++G) s += (double)part[G * slab + o1];
-      if (u < g.sym_h / 2) {
-        size_t o2 = (size_t)(g.U + u) * cols + (size_t)cip * KK + ky * K + (K - 1 - kx);
-        for (int G = 0; G < g.wgrad_G; ++G) s += (double)part[G * slab + o2];
-      }
-      if (dw) dw[i] += (float)s;
-    } else if (db) {
-      int co = (int)(i - nW);
-      double s = 0.0;
-      for (int G = 0; G < g.wgrad_G; ++G) s += (double)part[G * slab + (size_t)co * cols + (size_t)g.CinP * KK];
-      db[co] += (float)s;
+      o1 = (size_t)u * cols + (size_t)cip * KK + ky * K + kx;
+      if (u < g.sym_h / 2) { two = true; o2 = (size_t)(g.U + u) * cols + (size_t)cip * KK + ky * K + (K - 1 - kx); }
+    } else {
+      o1 = (size_t)(i - nW) * cols + (size_t)g.CinP * KK;
     }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int G = w;
+    for (; G + 12 < g.wgrad_G; G += 16) {
+      a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + 4) * slab + o1];
+      a2 += part[(size_t)(G + 8) * slab + o1]; a3 += part[(size_t)(G + 12) * slab + o1];
+      if (two) {
+        a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + 4) * slab + o2];
+        a2 += part[(size_t)(G + 8) * slab + o2]; a3 += part[(size_t)(G + 12) * slab + o2];
+      }
+    }
+    for (; G < g.wgrad_G; G += 4) {
+      a0 += part[(size_t)G * slab + o1];
+      if (two) a0 += part[(size_t)G * slab + o2];
+    }
+    s = (a0 + a1) + (a2 + a3);
+  }
+  red[w][e] = s;
+  __syncthreads();
+  if (w == 0 && i < total) {
+    float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (i < nW) { if (dw) dw[i] += r; }
+    else if (db) db[i - nW] += r;
   }
 }
 
@@ -192,7 +212,7 @@ int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float*
   if (rc) return rc;
   if (!partials || (!dw_unique && !dbias)) return MC_EINVAL;
   size_t total = (size_t)g.U * g.Cin * g.K * g.K + g.Cout;
-  int blocks = (int)((total + 255) / 256);
+  int blocks = (int)((total + 63) / 64);
   hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (const float*)partials,
                      dw_unique, dbias);
   MC_CHECK_LAUNCH();

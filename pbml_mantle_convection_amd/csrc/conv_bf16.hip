@@ -240,83 +240,134 @@ __global__ __launch_bounds__(256) void k_conv_mfma_bf16(ConvGeom g, const bf16_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// filter gradient (first version): tile-local f32 reduction on the vector ALU from bf16 tiles.
-// Same decomposition and partial layout as the f32 path (conv_f32.hip).  [MFMA version: see k_wgrad_mfma]
+// filter gradient on the matrix cores:
+//   dW[co][ci][ky][kx] = sum_{n,oy,ox} dy[n][co][oy][ox] * xpad[n][ci][oy+ky][ox+kx]
+// as D[i = co][j = ci] += A[i][k] B[k][j] with k = 32 consecutive output pixels of one row, one MFMA per
+// (tap, co-tile) and k-group.  Both operands need the PIXEL index on the MFMA k axis while the CB8 tiles in
+// LDS hold 8 CHANNELS per 16-byte vector: the transposition is done by ds_read_b64_tr_b16 (4 pixels x 16
+// channels per 16-lane group, delivered channel-per-lane) — two reads per fragment, any tap shift stays
+// 16-byte aligned because a pixel step is a whole vector.  Plane strides are == 4 (mod 16) slots so the
+// two channel-block planes of a read land on disjoint banks.
+//
+// Block (G, chunk, co-group): loops over (image, 16x32-pixel tile) work items; wave w owns taps w, w+4, ...
+// (7/6/6/6 of 25) for NTW co-tiles; wave 3 also accumulates the bias gradient through an all-ones B fragment.
+// Partials: [G][CoutP][CinP*K*K + 1] f32, combined deterministically by k_wgrad_finalize.
 // ------------------------------------------------------------------------------------------------
-constexpr int TS = 16;
-template <int K>
-__global__ __launch_bounds__(256) void k_wgrad_direct_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
-                                                           const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
-                                                           float* __restrict__ part) {
-  constexpr int TI = TS + K - 1;
-  __shared__ float xs[TI * TI][8];
-  __shared__ float dys[TS * TS][16];
-  const int cb = blockIdx.y, cog = blockIdx.z, co0 = cog * 16;
-  const int t = threadIdx.x;
-  const int tap = t >> 3, ci = t & 7;
-  const bool wthread = t < 8 * K * K;
-  const bool bthread = (cb == 0) && t >= 8 * K * K && t < 8 * K * K + 16;
-  const int ky = tap / K, kx = tap % K;
-  float acc[16];
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+__device__ __forceinline__ bf16x8 tr_frag(const short* base_lo) {
+  // base_lo: this lane's address for pixels 8g..8g+3; pixels 8g+4..8g+7 are 4 slots (64 bytes) further
+  v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)base_lo);
+  v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(base_lo + 32));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+constexpr int WTH = 16, WTW = 32;      // work-item tile (output pixels)
+
+template <int K, int NTW>
+__global__ __launch_bounds__(256) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
+                                                         const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
+                                                         float* __restrict__ part, int tiles_x, int tiles) {
+  constexpr int KK = K * K;
+  constexpr int TIH = WTH + K - 1, TIW = WTW + K - 1;
+  constexpr int XPS = ((TIH * TIW + 15) / 16) * 16 + 4;       // x plane stride (slots), == 4 mod 16
+  constexpr int DPS = WTH * WTW + 4;                          // dy plane stride (slots)
+  constexpr int NTAP = (KK + 3) / 4;                          // taps per wave (upper bound)
+  __shared__ uint4 xs[2 * XPS];
+  __shared__ uint4 ds[NTW * 2 * DPS];
+  const int chunk = blockIdx.y, cog = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
+  // per-lane short offsets (2-byte units) inside a plane pair for pixel 8g + q of a row start
+  const int lane_x = ((p >> 1) * XPS + 8 * gq + q) * 8 + (p & 1) * 4;
+  const int lane_d = ((p >> 1) * DPS + 8 * gq + q) * 8 + (p & 1) * 4;
+  const short* xs_s = reinterpret_cast<const short*>(xs);
+  const short* ds_s = reinterpret_cast<const short*>(ds);
+
+  f32x4 acc[NTAP][NTW];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float bacc = 0.f;
-  const bf16_t* src = cb < g.CB0 ? x0 : x1;
-  const int scb = cb < g.CB0 ? cb : cb - g.CB0;
-  const int sC8 = cb < g.CB0 ? g.CB0 : g.CB1;
-  const int work = g.N * g.tiles;
+  for (int a = 0; a < NTAP; ++a)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  static_assert(3 + 4 * (NTAP - 1) >= KK, "wave 3 needs a free accumulator slot for the bias gradient");
+  const bool do_bias = (wave == 3) && (chunk == 0);
+  const bf16x8 ones = (bf16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  const int work = g.N * tiles;
   for (int wi = blockIdx.x; wi < work; wi += gridDim.x) {
-    const int n = wi / g.tiles, tile = wi % g.tiles;
-    const int ty0 = (tile / g.tiles_x) * TS, tx0 = (tile % g.tiles_x) * TS;
+    const int n = wi / tiles, tile = wi % tiles;
+    const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     __syncthreads();
-    for (int i = t; i < TI * TI; i += 256) {
-      int r = i / TI, c = i % TI;
-      int sy = pad_map(ty0 + r - g.pad, g.H, g.pad_mode), sx = pad_map(tx0 + c - g.pad, g.W, g.pad_mode);
-      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (sy >= 0 && sx >= 0) V8<bf16_t>::ld(src + cb8_index(n, scb, sy, sx, sC8, g.H, g.W), v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xs[i][j] = v[j];
+    for (int i = threadIdx.x; i < 2 * TIH * TIW; i += 256) {
+      int cb = i / (TIH * TIW);
+      int rem = i - cb * (TIH * TIW);
+      int r = rem / TIW, c = rem - r * TIW;
+      int gcb = chunk * 2 + cb;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gcb < g.CBin) {
+        int sy = pad_map(ty0 + r - g.pad, g.H, g.pad_mode), sx = pad_map(tx0 + c - g.pad, g.W, g.pad_mode);
+        if (sy >= 0 && sx >= 0) {
+          const bf16_t* src = gcb < g.CB0 ? x0 : x1;
+          int scb = gcb < g.CB0 ? gcb : gcb - g.CB0;
+          int sC8 = gcb < g.CB0 ? g.CB0 : g.CB1;
+          v = *reinterpret_cast<const uint4*>(src + cb8_index(n, scb, sy, sx, sC8, g.H, g.W));
+        }
+      }
+      xs[cb * XPS + rem] = v;
     }
-    {
-      int r = t >> 4, c = t & 15;
+    for (int i = threadIdx.x; i < NTW * 2 * WTH * WTW; i += 256) {
+      int pl = i / (WTH * WTW);                     // plane = co-tile * 2 + half
+      int rem = i - pl * (WTH * WTW);
+      int r = rem / WTW, c = rem - r * WTW;
+      int cob = (cog * NTW) * 2 + pl;
       int oy = ty0 + r, ox = tx0 + c;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (cob < g.CBout && oy < g.Ho && ox < g.Wo)
+        v = *reinterpret_cast<const uint4*>(dy + cb8_index(n, cob, oy, ox, g.CBout, g.Ho, g.Wo));
+      ds[pl * DPS + rem] = v;
+    }
+    __syncthreads();
+    for (int row = 0; row < WTH; ++row) {
+      bf16x8 a[NTW];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        int cob = cog * 2 + half;
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (oy < g.Ho && ox < g.Wo && cob < g.CBout) V8<bf16_t>::ld(dy + cb8_index(n, cob, oy, ox, g.CBout, g.Ho, g.Wo), v);
+      for (int t = 0; t < NTW; ++t) a[t] = tr_frag(ds_s + (t * 2 * DPS + row * WTW) * 8 + lane_d);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dys[t][half * 8 + j] = v[j];
+      for (int ti = 0; ti < NTAP; ++ti) {
+        int tap = wave + 4 * ti;
+        if (tap < KK) {
+          int ky = tap / K, kx = tap % K;
+          bf16x8 b = tr_frag(xs_s + ((row + ky) * TIW + kx) * 8 + lane_x);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[ti][t], 0, 0, 0);
+        }
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          acc[NTAP - 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], ones, acc[NTAP - 1][t], 0, 0, 0);
       }
     }
-    __syncthreads();
-    if (wthread) {
-      for (int py = 0; py < TS; ++py)
-#pragma unroll 4
-        for (int px = 0; px < TS; ++px) {
-          float xv = xs[(py + ky) * TI + px + kx][ci];
-          const float4* d4 = reinterpret_cast<const float4*>(dys[py * TS + px]);
-          float4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
-          acc[0] = fmaf(xv, d0.x, acc[0]); acc[1] = fmaf(xv, d0.y, acc[1]); acc[2] = fmaf(xv, d0.z, acc[2]); acc[3] = fmaf(xv, d0.w, acc[3]);
-          acc[4] = fmaf(xv, d1.x, acc[4]); acc[5] = fmaf(xv, d1.y, acc[5]); acc[6] = fmaf(xv, d1.z, acc[6]); acc[7] = fmaf(xv, d1.w, acc[7]);
-          acc[8] = fmaf(xv, d2.x, acc[8]); acc[9] = fmaf(xv, d2.y, acc[9]); acc[10] = fmaf(xv, d2.z, acc[10]); acc[11] = fmaf(xv, d2.w, acc[11]);
-          acc[12] = fmaf(xv, d3.x, acc[12]); acc[13] = fmaf(xv, d3.y, acc[13]); acc[14] = fmaf(xv, d3.z, acc[14]); acc[15] = fmaf(xv, d3.w, acc[15]);
-        }
-    } else if (bthread) {
-      int co = t - 8 * K * K;
-      for (int p = 0; p < TS * TS; ++p) bacc += dys[p][co];
-    }
   }
-  const int cols = g.CinP * K * K + 1;
+  // ---- write this block's partial slab
+  const int cols = g.CinP * KK + 1;
   float* pb = part + (size_t)blockIdx.x * g.CoutP * cols;
-  if (wthread) {
-    int cig = cb * 8 + ci;
+  const int cip = chunk * 16 + (lane & 15);
 #pragma unroll
-    for (int co = 0; co < 16; ++co)
-      if (co0 + co < g.CoutP) pb[(size_t)(co0 + co) * cols + (size_t)cig * K * K + tap] = acc[co];
-  } else if (bthread) {
-    int co = co0 + t - 8 * K * K;
-    if (co < g.CoutP) pb[(size_t)co * cols + (size_t)g.CinP * K * K] = bacc;
+  for (int ti = 0; ti < NTAP; ++ti) {
+    int tap = wave + 4 * ti;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int co = (cog * NTW + t) * 16 + gq * 4 + r;
+        if (co >= g.CoutP) continue;
+        if (tap < KK) {
+          if (cip < g.CinP) pb[(size_t)co * cols + (size_t)cip * KK + tap] = acc[ti][t][r];
+        } else if (do_bias && ti == NTAP - 1 && (lane & 15) == 0) {
+          pb[(size_t)co * cols + (size_t)g.CinP * KK] = acc[ti][t][r];
+        }
+      }
   }
 }
 
@@ -396,18 +447,18 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
 }
 
 int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s) {
-  // NOTE: the filter-gradient partial layout assumes 16x16 tiles; recompute the tiling for that
-  ConvGeom w = g;
-  w.tiles_x = (g.Wo + TS - 1) / TS; w.tiles_y = (g.Ho + TS - 1) / TS; w.tiles = w.tiles_x * w.tiles_y;
-  long work = (long)w.N * w.tiles;
-  if (w.wgrad_G > work) w.wgrad_G = (int)work;
-  dim3 grid(w.wgrad_G, g.CBin, cdiv(g.CoutP, 16));
-  if (g.K == 5)
-    hipLaunchKernelGGL(k_wgrad_direct_bf16<5>, grid, dim3(256), 0, s, w, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)dy, (float*)part);
-  else if (g.K == 3)
-    hipLaunchKernelGGL(k_wgrad_direct_bf16<3>, grid, dim3(256), 0, s, w, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)dy, (float*)part);
-  else
-    return MC_EUNSUPPORTED;
+  const int tiles_x = (g.Wo + WTW - 1) / WTW, tiles_y = (g.Ho + WTH - 1) / WTH;
+  const int tiles = tiles_x * tiles_y;
+  const int ntiles = (g.Cout + 15) / 16;
+  const int ntw = pick_nt(ntiles) >= 2 ? 2 : 1;      // two co-tiles per block keep LDS at 55 KB (2-3 blocks per CU)
+  dim3 grid(g.wgrad_G, (g.CBin + 1) / 2, (ntiles + ntw - 1) / ntw);
+#define WLAUNCH(K, NTW)                                                                                              \
+  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1,     \
+                     (const bf16_t*)dy, (float*)part, tiles_x, tiles)
+  if (g.K == 5) { if (ntw == 1) WLAUNCH(5, 1); else WLAUNCH(5, 2); }
+  else if (g.K == 3) { if (ntw == 1) WLAUNCH(3, 1); else WLAUNCH(3, 2); }
+  else return MC_EUNSUPPORTED;
+#undef WLAUNCH
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -42,11 +42,24 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.dtype = d->dtype;
   g.out_f32 = (d->dtype == MC_BF16) ? d->out_f32 : 0;
   if (g.out_f32 && (d->c_out > 16 || d->c_out_split != 0)) return MC_EUNSUPPORTED;
+  // number of partial slabs of the filter-gradient reduction: enough workgroups to fill the chip
+  // (~1024 with the other grid dimensions), bounded by 64 MiB of partials and by the work available
   long slab = (long)g.CoutP * ((long)g.CinP * g.K * g.K + 1) * 4;
-  long G = (64L << 20) / slab;
-  if (G < 32) G = 32;
-  if (G > 1024) G = 1024;
-  long work = (long)g.N * g.tiles;
+  long cap = (64L << 20) / slab;
+  if (cap < 32) cap = 32;
+  long G, work;
+  if (g.dtype == MC_BF16) {
+    int ntiles = (g.Cout + 15) / 16;
+    int ntw = (ntiles % 2 == 0) ? 2 : 1;
+    long other = (long)((g.CBin + 1) / 2) * ((ntiles + ntw - 1) / ntw);
+    G = (1024 + other - 1) / other;
+    if (G < 32) G = 32;
+    work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
+  } else {
+    G = 1024;
+    work = (long)g.N * g.tiles;
+  }
+  if (G > cap) G = cap;
   if (G > work) G = work;
   g.wgrad_G = (int)G;
   return MC_OK;
