@@ -35,7 +35,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=None)
     p.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     p.add_argument("--size", type=int, nargs=2, default=[506, 506], metavar=("H", "W"))
-    p.add_argument("--precision", type=str, default=os.environ.get("MANTLE_BENCH_PRECISION", "fp32"),
+    p.add_argument("--precision", type=str, default=os.environ.get("MANTLE_BENCH_PRECISION", "bf16"),
                    choices=["bf16", "fp32"])
     p.add_argument("--lambda-mom", type=float, default=1e-6, help="weight of the Stokes momentum residual (CFG-3)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")

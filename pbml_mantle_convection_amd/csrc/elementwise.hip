@@ -359,28 +359,73 @@ __global__ void k_bicubic_fwd(const T* __restrict__ x, int C8, int Hi, int Wi, i
   }
 }
 
+// adjoint of the bicubic upsample.  One block = an 8 x 8 tile of input (low-res) pixels of one channel block:
+// the (folded) output-gradient window the tile touches is staged in LDS once (the transposed tap lists of 8
+// consecutive input pixels cover <= WIN consecutive output pixels), then each thread gathers its pixel from LDS.
+constexpr int BT = 8, BWIN = 40;
 template <typename T>
-__global__ void k_bicubic_bwd(mc_grad_src g, int C8, int Hi, int Wi, const int* __restrict__ tys,
-                              const int* __restrict__ tyj, const float* __restrict__ tyw,
-                              const int* __restrict__ txs, const int* __restrict__ txj,
-                              const float* __restrict__ txw, T* __restrict__ dx) {
+__global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int Hi, int Wi, const int* __restrict__ tys,
+                                                     const int* __restrict__ tyj, const float* __restrict__ tyw,
+                                                     const int* __restrict__ txs, const int* __restrict__ txj,
+                                                     const float* __restrict__ txw, T* __restrict__ dx, int tiles_x) {
+  __shared__ float win[BWIN][BWIN][8];
+  __shared__ int lim[4];
   const int n = blockIdx.z, cb = blockIdx.y;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wi; i += gridDim.x * blockDim.x) {
-    int yi = i / Wi, xi = i % Wi;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int a = tys[yi]; a < tys[yi + 1]; ++a) {
+  const int ty0 = (blockIdx.x / tiles_x) * BT, tx0 = (blockIdx.x % tiles_x) * BT;
+  const int ty1 = min(ty0 + BT, Hi), tx1 = min(tx0 + BT, Wi);
+  if (threadIdx.x == 0) {
+    // output ranges referenced by this tile (tap lists are sorted by output index)
+    int ylo = 1 << 30, yhi = -1, xlo = 1 << 30, xhi = -1;
+    for (int i = ty0; i < ty1; ++i)
+      if (tys[i + 1] > tys[i]) { ylo = min(ylo, tyj[tys[i]]); yhi = max(yhi, tyj[tys[i + 1] - 1]); }
+    for (int i = tx0; i < tx1; ++i)
+      if (txs[i + 1] > txs[i]) { xlo = min(xlo, txj[txs[i]]); xhi = max(xhi, txj[txs[i + 1] - 1]); }
+    lim[0] = ylo; lim[1] = yhi; lim[2] = xlo; lim[3] = xhi;
+  }
+  __syncthreads();
+  const int ylo = lim[0], yhi = lim[1], xlo = lim[2], xhi = lim[3];
+  const int wh = yhi - ylo + 1, ww = xhi - xlo + 1;
+  const bool fits = wh > 0 && ww > 0 && wh <= BWIN && ww <= BWIN;
+  if (fits) {
+    for (int i = threadIdx.x; i < wh * ww; i += 256) {
+      int r = i / ww, c = i % ww;
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      grad_fetch_add<T>(g, n, cb, ylo + r, xlo + c, C8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) win[r][c][j] = v[j];
+    }
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / (BT * 4), lx = (threadIdx.x / 4) % BT, part = threadIdx.x & 3;   // 4 threads per pixel
+  const int yi = ty0 + ly, xi = tx0 + lx;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (yi < ty1 && xi < tx1) {
+    int a0 = tys[yi], a1 = tys[yi + 1];
+    for (int a = a0 + part; a < a1; a += 4) {
       int yo = tyj[a];
       float wa = tyw[a];
       for (int b = txs[xi]; b < txs[xi + 1]; ++b) {
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
         float w = wa * txw[b];
+        float v[8];
+        if (fits) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = win[yo - ylo][txj[b] - xlo][j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
       }
     }
-    V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 1, 64);
+    acc[j] += __shfl_xor(acc[j], 2, 64);
+  }
+  if (part == 0 && yi < ty1 && xi < tx1) V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
 }
 
 // =================================================================================================
@@ -700,10 +745,11 @@ int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int3
   if (rc) return rc;
   if (gs->hs != ho || gs->ws != wo) return MC_EINVAL;
   int C8 = (c + 7) / 8;
-  dim3 g = grid3(hi * wi, C8, n, 256, 4096);
+  int tiles_x = cdiv(wi, BT), tiles_y = cdiv(hi, BT);
+  dim3 g(tiles_x * tiles_y, C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_bwd<float>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (float*)dx);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_bwd<bf16_t>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (bf16_t*)dx);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_bwd<float>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (float*)dx, tiles_x);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_bwd<bf16_t>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (bf16_t*)dx, tiles_x);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
