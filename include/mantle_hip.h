@@ -47,8 +47,8 @@ enum { MC_POST_NONE = 0,   /* plain nn.Conv2d (Unet conv[-1], ConvAE final conv)
 /* where the gradient w.r.t. an activated tensor comes from (backward) */
 enum { MC_GSRC_NONE = 0,
        MC_GSRC_PLAIN = 1,      /* CB8 tensor of the same H x W                                         */
-       MC_GSRC_PADFOLD = 2,    /* dgrad output on the padded domain (H+2p)x(W+2p); the padding          */
-                               /* adjoint (reflect / replicate fold) is applied on read                */
+       MC_GSRC_PADFOLD = 2,    /* dgrad output on the padded domain (H+2p)x(W+2p) whose halo has been      */
+                               /* folded onto the interior by mc_fold_padded: read at offset (p, p)    */
        MC_GSRC_PADFOLD_POOL = 3 /* same, through the adjoint of AvgPool(f): value/f^2 at (y/f, x/f)   */ };
 
 typedef struct {
@@ -125,6 +125,13 @@ int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const
                     void* partials, void* stream);
 int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float* dw_unique,
                              float* dbias, void* stream);
+
+/* Adjoint of F.pad(mode) on a padded-domain gradient (output of mc_conv2d in input-gradient mode):
+ * adds the halo of buf [n][c8][hs+2p][ws+2p][8] onto the interior positions it was padded from
+ * (reflect: mirror about the edge pixel; replicate: onto the edge pixel; zeros: nothing). In place;
+ * touches only the O(p (H+W)) border pixels. */
+int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode,
+                   int32_t dtype, void* stream);
 
 /* ---- GroupNorm + activation (FluidLayer :788-799; Unet :2016-2021) ------------------------ */
 /* (mean, rstd) per (n, group) from conv stat partials; eps 1e-5, biased variance.  Also emits

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mc_wgrad_partial_bytes": (_sz, [_CD]),
     "mc_conv2d_wgrad": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp]),
     "mc_conv2d_wgrad_finalize": (C.c_int, [_CD, _vp, _vp, _vp, _vp]),
+    "mc_fold_padded": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _vp]),

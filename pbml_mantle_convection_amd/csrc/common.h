@@ -107,6 +107,28 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   }
 }
 
+// bf16-mode GELU / GELU': erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) sharing ONE exp between the cdf and the pdf
+// (erf(z/sqrt2) needs exp(-z^2/2), which is also the Gaussian pdf) -> rcp + exp + ~10 FMA instead of erff + expf.
+__device__ __forceinline__ void gelu_cdf_pdf(float z, float& cdf, float& pdf) {
+  float x = fabsf(z) * 0.70710678118654752440f;
+  float e = __expf(-x * x);
+  float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  float erf_abs = 1.0f - poly * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
+  pdf = 0.39894228040143267794f * e;
+}
+template <bool FAST> __device__ __forceinline__ float act_fwd_t(float z, int act) {
+  if (FAST && act == MC_ACT_GELU) { float c, p; gelu_cdf_pdf(z, c, p); return z * c; }
+  return act_fwd(z, act);
+}
+template <bool FAST> __device__ __forceinline__ float act_bwd_t(float z, int act) {
+  if (FAST && act == MC_ACT_GELU) { float c, p; gelu_cdf_pdf(z, c, p); return fmaf(z, p, c); }
+  return act_bwd(z, act);
+}
+template <typename T> struct FastMath { static constexpr bool value = false; };
+template <> struct FastMath<bf16_t> { static constexpr bool value = true; };
+
 // ---- wave / block reductions (wave = 64) --------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -139,6 +161,7 @@ __device__ __forceinline__ int fold_candidates(int i, int n, int p, int mode, in
 template <typename T>
 __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int cb, int y, int x, int C8,
                                                float (&acc)[8]) {
+  // PADDED sources have had the padding adjoint folded onto their interior by mc_fold_padded: read at offset pad.
   if (g.kind == MC_GSRC_NONE || g.ptr == nullptr) return;
   const T* base = reinterpret_cast<const T*>(g.ptr);
   float v[8];
@@ -151,18 +174,11 @@ __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int 
   float scale = 1.0f;
   int yy = y, xx = x;
   if (g.kind == MC_GSRC_PADFOLD_POOL) {
-    yy = y / g.pool; xx = x / g.pool;
+    if (g.pool == 2) { yy = y >> 1; xx = x >> 1; } else { yy = y / g.pool; xx = x / g.pool; }
     if (yy >= g.hs || xx >= g.ws) return;   // floor mode: trailing rows/cols are not pooled
     scale = 1.0f / (float)(g.pool * g.pool);
   }
-  const int Hp = g.hs + 2 * g.pad, Wp = g.ws + 2 * g.pad;
-  int cy[6], cx[6];
-  int ny = fold_candidates(yy, g.hs, g.pad, g.pad_mode, cy);
-  int nx = fold_candidates(xx, g.ws, g.pad, g.pad_mode, cx);
-  for (int a = 0; a < ny; ++a)
-    for (int b = 0; b < nx; ++b) {
-      V8<T>::ld(base + cb8_index(n, cb, cy[a], cx[b], C8, Hp, Wp), v);
+  V8<T>::ld(base + cb8_index(n, cb, yy + g.pad, xx + g.pad, C8, g.hs + 2 * g.pad, g.ws + 2 * g.pad), v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += scale * v[j];
-    }
+  for (int j = 0; j < 8; ++j) acc[j] += scale * v[j];
 }

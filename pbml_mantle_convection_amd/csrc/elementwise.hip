@@ -127,6 +127,8 @@ __global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, 
 // =================================================================================================
 // a = act(GN(y)) [+ AvgPool(POOL)(a)]
 // =================================================================================================
+constexpr int GN_ROWS = 8;
+
 struct GnArgs {
   int N, C, C8, H, W, groups, cpg, post, act;
   const float* stats;
@@ -174,7 +176,7 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
           V8<T>::ld(y + idx, v);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+            v[j] = act_fwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], act);
             acc[j] += v[j];
           }
           V8<T>::st(out + idx, v);
@@ -228,20 +230,19 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __rest
     } else { mean[j] = 0.f; rstd[j] = 0.f; }
   }
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int HW = a.H * a.W;
-  for (int i = blk * blockDim.x + threadIdx.x; i < HW; i += nblk * blockDim.x) {
-    int yy = i / a.W, xx = i % a.W;
-    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
-    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
-    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+  for (int yy = blk; yy < a.H; yy += nblk)
+    for (int xx = threadIdx.x; xx < a.W; xx += blockDim.x) {
+      float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
+      grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
+      grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float dz = da[j] * act_bwd(v[j] * sc[j] + sh[j], a.act);
-      s1[j] += dz;
-      s2[j] += dz * (v[j] - mean[j]) * rstd[j];
+      for (int j = 0; j < 8; ++j) {
+        float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
+        s1[j] += dz;
+        s2[j] += dz * (v[j] - mean[j]) * rstd[j];
+      }
     }
-  }
   __shared__ float red[4][16];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -309,9 +310,10 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
       } else { ga[j] = 1.f; rstd[j] = 1.f; }
     }
   }
-  const int HW = a.H * a.W;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-    int yy = i / a.W, xx = i % a.W;
+  // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over
+  // >= 8 vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s)
+  for (int yy = blockIdx.x * GN_ROWS; yy < min((int)(blockIdx.x + 1) * GN_ROWS, a.H); ++yy)
+  for (int xx = threadIdx.x; xx < a.W; xx += blockDim.x) {
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
     size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
     V8<T>::ld(y + idx, v);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
     grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float dz = da[j] * act_bwd(v[j] * sc[j] + sh[j], a.act);
+      float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
       if (a.post == MC_POST_GN_ACT) {
         float yh = (v[j] - mean[j]) * rstd[j];
         o[j] = rstd[j] * (dz * ga[j] - m1[j] - yh * m2[j]);
@@ -328,6 +330,45 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
       }
     }
     V8<T>::st(dy + idx, o);
+  }
+}
+
+// in-place adjoint of F.pad on a padded-domain gradient: one thread per border TARGET pixel (a pixel of the
+// interior frame of thickness p+1) gathers its halo sources; sources are halo positions only, so no hazards.
+template <typename T>
+__global__ void k_fold_padded(T* __restrict__ buf, int C8, int H, int W, int p, int mode, int all) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  const int t = p + 1;
+  const int band = all ? H * W : 2 * t * W;         // top + bottom bands (all columns); tiny images: every pixel
+  const int side = all ? 0 : (H - 2 * t) * 2 * t;   // left + right bands of the remaining rows
+  const int Hp = H + 2 * p, Wp = W + 2 * p;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < band + side; i += gridDim.x * blockDim.x) {
+    int yy, xx;
+    if (all) {
+      yy = i / W;
+      xx = i - yy * W;
+    } else if (i < band) {
+      int r = i / W;
+      xx = i - r * W;
+      yy = r < t ? r : H - 2 * t + r;
+    } else {
+      int k = i - band;
+      int r = k / (2 * t), c = k - r * 2 * t;
+      yy = t + r;
+      xx = c < t ? c : W - 2 * t + c;
+    }
+    int cy[6], cx[6];
+    int ny = fold_candidates(yy, H, p, mode, cy), nx = fold_candidates(xx, W, p, mode, cx);
+    if (ny == 1 && nx == 1) continue;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        float v[8];
+        V8<T>::ld(buf + cb8_index(n, cb, cy[a], cx[b], C8, Hp, Wp), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    V8<T>::st(buf + cb8_index(n, cb, yy + p, xx + p, C8, Hp, Wp), acc);
   }
 }
 
@@ -634,7 +675,7 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   if (pool != 1 && pool != 2 && pool != 4) return MC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int per = cdiv(h, pool) * cdiv(w, pool);
-  dim3 g = grid3(per, a.C8, n, 256, 4096);
+  dim3 g(max(1, min(cdiv(per, 256 * 8), 4096)), a.C8, n);
 #define GN_LAUNCH(T, P) hipLaunchKernelGGL((k_gn_act_fwd<T, P>), g, dim3(256), 0, s, a, (const T*)y, (T*)a_out, (T*)pooled)
   if (dtype == MC_F32) { if (pool == 1) GN_LAUNCH(float, 1); else if (pool == 2) GN_LAUNCH(float, 2); else GN_LAUNCH(float, 4); }
   else if (dtype == MC_BF16) { if (pool == 1) GN_LAUNCH(bf16_t, 1); else if (pool == 2) GN_LAUNCH(bf16_t, 2); else GN_LAUNCH(bf16_t, 4); }
@@ -713,10 +754,26 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   if (!y || !dy || !g0 || (post == MC_POST_GN_ACT && !m12)) return MC_EINVAL;
   if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
   if (post == MC_POST_NONE) a.act = MC_ACT_NONE;
-  dim3 g = grid3(h * w, a.C8, n, 256, 4096);
+  dim3 g(cdiv(h, GN_ROWS), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_bwd_apply<float>, g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_bwd_apply<bf16_t>, g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode, int32_t dtype,
+                   void* stream) {
+  if (!buf || n <= 0 || c <= 0 || hs <= 0 || ws <= 0 || pad < 0 || pad > 2) return MC_EINVAL;
+  if (pad == 0 || pad_mode == MC_PAD_ZEROS) return MC_OK;
+  int C8 = (c + 7) / 8, t = pad + 1;
+  int all = (hs < 2 * t || ws < 2 * t) ? 1 : 0;
+  int total = all ? hs * ws : 2 * t * ws + (hs - 2 * t) * 2 * t;
+  dim3 g(cdiv(total, 256), C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded<float>, g, dim3(256), 0, s, (float*)buf, C8, hs, ws, pad, pad_mode, all);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_fold_padded<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;

@@ -505,6 +505,8 @@ class Engine:
                 self._probe_end(e["ddesc"], "dgrad " + node.name)
                 for s, buf in zip(srcs, dxp):
                     if s.requires_grad:
+                        # adjoint of the padding: fold the halo onto the interior once, consumers read at an offset
+                        L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
 
     # -------------------------------------------------------------- measurement hooks (bench.py)
