@@ -67,6 +67,15 @@ __device__ __forceinline__ int pad_map(int i, int n, int mode) {
   return (i >= 0 && i < n) ? i : -1;
 }
 
+// branch-free variant for batched staging loads: returns a clamped (always valid) index and sets ok
+__device__ __forceinline__ int pad_map_sel(int i, int n, int mode, bool& ok) {
+  int refl = i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i);
+  int clmp = min(max(i, 0), n - 1);
+  int j = mode == MC_PAD_REFLECT ? refl : clmp;
+  ok = (mode != MC_PAD_ZEROS) || (i >= 0 && i < n);
+  return min(max(j, 0), n - 1);
+}
+
 // ---- activations and derivatives (nn.GELU() exact erf form etc.) -------------------------------
 __device__ __forceinline__ float act_fwd(float z, int act) {
   switch (act) {

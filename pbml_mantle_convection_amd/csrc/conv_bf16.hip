@@ -73,13 +73,23 @@ __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad,
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward / input-gradient kernel
+// forward / input-gradient kernel (persistent over work items, register-prefetched staging)
+//
+// A workgroup walks a list of stages (work item = (image, tile); stage = one 16-channel chunk of it).
+// The global loads of stage t+1 are issued into registers right after stage t has been written to LDS
+// and retire under stage t's MFMA loop (issue-early / write-late split staging); padding is resolved
+// by clamped addressing + select (or skipped entirely for interior tiles), so the loads batch.
+//
+// MFMA orientation: A = filter fragment (M = 16 output channels), B = input fragment (N = 16 pixels),
+// so the accumulator holds, per lane, FOUR CONSECUTIVE OUTPUT CHANNELS of ONE pixel (C/D: col = lane&15 =
+// pixel, row = 4*(lane>>4)+reg = channel): exactly 8 contiguous bytes of the CB8 output vector.  The
+// epilogue therefore stores straight from registers (no LDS transpose, no extra barriers).
 // ------------------------------------------------------------------------------------------------
 template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false>
-__global__ __launch_bounds__(256) void k_conv_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
-                                                        const bf16_t* __restrict__ x1, const bf16_t* __restrict__ bank,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ y0,
-                                                        bf16_t* __restrict__ y1, float* __restrict__ part, int n_groups) {
+__global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
+    ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ bank,
+    const float* __restrict__ bias, bf16_t* __restrict__ y0, bf16_t* __restrict__ y1, float* __restrict__ part,
+    int n_groups) {
   constexpr int TIH = TH + K - 1, TIW = TW + K - 1;
   constexpr int PLANE = (TIH * TIW + 15) / 16 * 16;           // 16-byte slots per channel-block plane
   constexpr int STEPS = KSteps<K>::steps;
@@ -88,153 +98,195 @@ __global__ __launch_bounds__(256) void k_conv_mfma_bf16(ConvGeom g, const bf16_t
   constexpr int IN_SLOTS = CHUNK_CB * PLANE;
   constexpr int W_SLOTS = STEPS * NT * 64;
   static_assert(!OUT_F32 || NT == 1, "f32 output is for the single-N-tile configuration");
-  constexpr int OUT_SLOTS = TH * TW * NT * (OUT_F32 ? 4 : 2);  // [pixel][NT*16 couts] bf16 (f32) = NT*2 (4) slots per pixel
-  constexpr int LDS_SLOTS = (IN_SLOTS + W_SLOTS) > OUT_SLOTS ? (IN_SLOTS + W_SLOTS) : OUT_SLOTS;
-  __shared__ uint4 lds[LDS_SLOTS];
+  constexpr int IN_ELEMS = CHUNK_CB * TIH * TIW;
+  constexpr int IN_ITERS = (IN_ELEMS + 255) / 256;
+  constexpr int W_ITERS = (W_SLOTS + 255) / 256;
+  __shared__ uint4 lds[IN_SLOTS + W_SLOTS];
   __shared__ float red[4][NT * 16 * 2];
   uint4* in_s = lds;
   uint4* w_s = lds + IN_SLOTS;
 
-  const int tile = blockIdx.x, grp = blockIdx.y, n = blockIdx.z;
-  const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
+  const int grp = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, gq = lane >> 4;
   const int ntile0 = grp * NT;                                  // first global N-tile of this block
   const int ntiles_total = gridDim.y * NT;
   const int chunks = (g.CBin + CHUNK_CB - 1) / CHUNK_CB;
+  const int items = g.N * g.tiles;
+  const int my_items = (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total_stages = my_items * chunks;
+  const ptrdiff_t x1_delta = x1 ? reinterpret_cast<const char*>(x1) - reinterpret_cast<const char*>(x0) : (ptrdiff_t)0;
 
-  // per-lane A offsets (16-byte slots) for every K-step
-  int aoff[STEPS];
+  uint4 rin[IN_ITERS];
+  auto prefetch = [&](int t) {
+    const int jitem = t / chunks, ck = t - jitem * chunks;
+    const int wi = blockIdx.x + jitem * gridDim.x;
+    const int n = wi / g.tiles, tile = wi - n * g.tiles;
+    const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
+    // interior tile (uniform): the whole input window lies inside the image -> plain strided addressing
+    const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    int j = 4 * s + gq;
-    int tap = j / CHUNK_CB, cb = j % CHUNK_CB;
-    if (tap >= K * K) { tap = 0; }                              // dummy pair: weights are zero
-    aoff[s] = cb * PLANE + (tap / K) * TIW + (tap % K);
-  }
-  // M-tile bases of this wave: tile t = wave*MT + i -> (row, col0)
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int ck = 0; ck < chunks; ++ck) {
-    __syncthreads();
-    // ---- stage the input window of this chunk
-    for (int i = threadIdx.x; i < CHUNK_CB * TIH * TIW; i += 256) {
+    for (int it = 0; it < IN_ITERS; ++it) {
+      int i = threadIdx.x + it * 256;
+      if (i >= IN_ELEMS) i = IN_ELEMS - 1;                      // duplicate (harmless) load for the tail
       int cb = i / (TIH * TIW);
       int rem = i - cb * (TIH * TIW);
       int r = rem / TIW, c = rem - r * TIW;
       int gcb = ck * CHUNK_CB + cb;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (gcb < g.CBin) {
-        int sy = pad_map(ty0 + r - g.pad, g.H, g.pad_mode), sx = pad_map(tx0 + c - g.pad, g.W, g.pad_mode);
-        if (sy >= 0 && sx >= 0) {
-          const bf16_t* src = gcb < g.CB0 ? x0 : x1;
-          int scb = gcb < g.CB0 ? gcb : gcb - g.CB0;
-          int sC8 = gcb < g.CB0 ? g.CB0 : g.CB1;
-          v = *reinterpret_cast<const uint4*>(src + cb8_index(n, scb, sy, sx, sC8, g.H, g.W));
-        }
+      int gcc = min(gcb, g.CBin - 1);
+      bool second = gcc >= g.CB0;
+      int scb = second ? gcc - g.CB0 : gcc;
+      int sC8 = second ? g.CB1 : g.CB0;
+      const char* bp = reinterpret_cast<const char*>(x0) + (second ? x1_delta : (ptrdiff_t)0);
+      bool ok = gcb < g.CBin;
+      int sy, sx;
+      if (interior) {
+        sy = ty0 - g.pad + r; sx = tx0 - g.pad + c;
+      } else {
+        bool oky, okx;
+        sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
+        sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
+        ok = ok && oky && okx;
       }
-      in_s[cb * PLANE + rem] = v;
+      uint4 v = *reinterpret_cast<const uint4*>(bp + cb8_index(n, scb, sy, sx, sC8, g.H, g.W) * sizeof(bf16_t));
+      rin[it] = ok ? v : make_uint4(0, 0, 0, 0);
     }
-    // ---- stage this chunk's slice of the bank: [step][nt][lane]
-    {
-      const uint4* bsrc = reinterpret_cast<const uint4*>(bank) + (size_t)ck * STEPS * ntiles_total * 64;
-      for (int i = threadIdx.x; i < W_SLOTS; i += 256) {
-        int ln = i & 63;
-        int r = i >> 6;
-        int t = r % NT, s = r / NT;
-        w_s[i] = bsrc[((size_t)s * ntiles_total + ntile0 + t) * 64 + ln];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+      int i = threadIdx.x + it * 256;
+      if (i < IN_ELEMS) {
+        int cb = i / (TIH * TIW);
+        in_s[cb * PLANE + (i - cb * (TIH * TIW))] = rin[it];
       }
     }
+  };
+  // the bank slice changes only with the chunk: single-chunk layers (65 % of the FLOPs) stage it once
+  auto stage_weights = [&](int ck) {
+    const uint4* bsrc = reinterpret_cast<const uint4*>(bank) + (size_t)ck * STEPS * ntiles_total * 64;
+    uint4 rw[W_ITERS];
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      int i = min((int)threadIdx.x + it * 256, W_SLOTS - 1);
+      int ln = i & 63;
+      int r = i >> 6;
+      int tt = r % NT, ss = r / NT;
+      rw[it] = bsrc[((size_t)ss * ntiles_total + ntile0 + tt) * 64 + ln];
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      int i = threadIdx.x + it * 256;
+      if (i < W_SLOTS) w_s[i] = rw[it];
+    }
+  };
+
+  // per-lane bias of its four output channels per N-tile
+  float bv[NT][4];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int co = (ntile0 + tt) * 16 + gq * 4 + r;
+      bv[tt][r] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    }
+
+  f32x4 acc[MT][NT];
+  if (total_stages > 0) prefetch(0);
+  for (int t = 0; t < total_stages; ++t) {
+    const int jitem = t / chunks, ck = t - jitem * chunks;
+    if (ck == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                                            // LDS free: previous MFMA loop done
+    commit();
+    if (chunks > 1 || t == 0) stage_weights(ck);
     __syncthreads();
-    // ---- MFMA loop
-#pragma unroll
+    if (t + 1 < total_stages) prefetch(t + 1);                  // in flight during the MFMA loop
+    // ---- MFMA loop (rolled over the K-steps: the per-lane operand offset is recomputed per step)
+    const int wbase = (wave * MT / MTILES_X) * TIW + ((wave * MT) % MTILES_X) * 16 + m;
+#pragma unroll 1
     for (int s = 0; s < STEPS; ++s) {
-      bf16x8 b[NT];
+      int jp = 4 * s + gq;
+      int tap = jp / CHUNK_CB, cbk = jp % CHUNK_CB;
+      if (tap >= K * K) tap = 0;                                // dummy pair: its weights are zero
+      const uint4* ap = in_s + (cbk * PLANE + (tap / K) * TIW + (tap % K) + wbase);
+      bf16x8 wf[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const bf16x8*>(&w_s[(s * NT + t) * 64 + lane]);
+      for (int tt = 0; tt < NT; ++tt) wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(s * NT + tt) * 64 + lane]);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        int mt = wave * MT + i;
-        int row = mt / MTILES_X, col0 = (mt % MTILES_X) * 16;
-        bf16x8 a = *reinterpret_cast<const bf16x8*>(&in_s[row * TIW + col0 + m + aoff[s]]);
+        // M-tile i of this wave sits (i / MTILES_X) rows and (i % MTILES_X) * 16 columns from the wave's first
+        bf16x8 xf = *reinterpret_cast<const bf16x8*>(ap + (i / MTILES_X) * TIW + (i % MTILES_X) * 16);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[t], acc[i][t], 0, 0, 0);
+        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt], xf, acc[i][tt], 0, 0, 0);
       }
     }
-  }
+    if (ck != chunks - 1) continue;
 
-  // ---- epilogue: bias, statistics, transpose through LDS, 16-byte stores
-  __syncthreads();
-  bf16_t* out_s = reinterpret_cast<bf16_t*>(lds);               // [TH*TW][NT*16]
-  float* out_f = reinterpret_cast<float*>(lds);
-  float ssum[NT], ssq[NT];
+    // ---- epilogue of this work item, straight from the accumulators
+    const int wi = blockIdx.x + jitem * gridDim.x;
+    const int n = wi / g.tiles, tile = wi - n * g.tiles;
+    const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
+    float s1[NT][4], s2[NT][4];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    int co = (ntile0 + t) * 16 + m;                             // C/D: col = lane & 15
-    float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[tt][r] = 0.f; s2[tt][r] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      int mt = wave * MT + i;
-      int row = mt / MTILES_X, col0 = (mt % MTILES_X) * 16;
+      const int mt = wave * MT + i;
+      const int oy = ty0 + mt / MTILES_X, ox = tx0 + (mt % MTILES_X) * 16 + m;   // C/D: col = lane & 15 = pixel
+      const bool inb = oy < g.Ho && ox < g.Wo;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int px = col0 + gq * 4 + r;                             // C/D: row = (lane >> 4) * 4 + reg
-        float v = acc[i][t][r] + bv;
-        bool valid = (ty0 + row) < g.Ho && (tx0 + px) < g.Wo && co < g.Cout;
-        if (valid) { s1 += v; s2 += v * v; }
-        if (OUT_F32) out_f[(row * TW + px) * 16 + m] = co < g.Cout ? v : 0.f;
-        else out_s[(row * TW + px) * (NT * 16) + t * 16 + m] = f2bf(co < g.Cout ? v : 0.f);
+      for (int tt = 0; tt < NT; ++tt) {
+        const int cob = (ntile0 + tt) * 2 + (gq >> 1);          // C/D: row = 4*(lane>>4)+reg = output channel
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int co = (ntile0 + tt) * 16 + gq * 4 + r;
+          v[r] = co < g.Cout ? acc[i][tt][r] + bv[tt][r] : 0.f;
+          if (inb) { s1[tt][r] += v[r]; s2[tt][r] += v[r] * v[r]; }
+        }
+        if (inb && cob < g.CBout) {
+          if (OUT_F32) {
+            float* yf = reinterpret_cast<float*>(y0);
+            *reinterpret_cast<float4*>(yf + cb8_index(n, cob, oy, ox, g.CBout, g.Ho, g.Wo) + (gq & 1) * 4) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            bf16_t* dst = (g.split8 > 0 && cob >= g.split8)
+                              ? y1 + cb8_index(n, cob - g.split8, oy, ox, g.CBout - g.split8, g.Ho, g.Wo)
+                              : y0 + cb8_index(n, cob, oy, ox, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo);
+            *reinterpret_cast<uint2*>(dst + (gq & 1) * 4) = pk;
+          }
+        }
       }
     }
-    ssum[t] = s1; ssq[t] = s2;
-  }
-  if (part) {
+    if (part) {
+      // reduce over the 16 pixel lanes of each 16-lane group; lane m == 0 of group gq owns channels 4 gq .. 4 gq + 3
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float s1 = ssum[t], s2 = ssq[t];
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (lane < 16) { red[wave][(t * 16 + lane) * 2] = s1; red[wave][(t * 16 + lane) * 2 + 1] = s2; }
-    }
-  }
-  __syncthreads();
-  if (part && threadIdx.x < NT * 32) {
-    int co = ntile0 * 16 + (threadIdx.x >> 1);
-    if (co < g.CoutP) {
-      float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      part[(((size_t)n * g.tiles + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
-    }
-  }
-  if (OUT_F32) {
-    float* yf = reinterpret_cast<float*>(y0);
-    for (int i = threadIdx.x; i < TH * TW * 4; i += 256) {      // 16-byte pieces: 4 per pixel (16 f32 channels)
-      int q = i & 3, pix = i >> 2;
-      int row = pix / TW, px = pix % TW;
-      int oy = ty0 + row, ox = tx0 + px;
-      int cob = q >> 1;
-      if (oy < g.Ho && ox < g.Wo && cob < g.CBout)
-        *reinterpret_cast<uint4*>(yf + cb8_index(n, cob, oy, ox, g.CBout, g.Ho, g.Wo) + (q & 1) * 4) =
-            reinterpret_cast<const uint4*>(out_f)[pix * 4 + q];
-    }
-    return;
-  }
-  for (int i = threadIdx.x; i < TH * TW * NT * 2; i += 256) {
-    int cbl = i % (NT * 2);
-    int pix = i / (NT * 2);
-    int row = pix / TW, px = pix % TW;
-    int oy = ty0 + row, ox = tx0 + px;
-    int cob = ntile0 * 2 + cbl;
-    if (oy < g.Ho && ox < g.Wo && cob < g.CBout) {
-      uint4 v = reinterpret_cast<const uint4*>(out_s)[pix * (NT * 2) + cbl];
-      if (g.split8 > 0 && cob >= g.split8)
-        *reinterpret_cast<uint4*>(y1 + cb8_index(n, cob - g.split8, oy, ox, g.CBout - g.split8, g.Ho, g.Wo)) = v;
-      else
-        *reinterpret_cast<uint4*>(y0 + cb8_index(n, cob, oy, ox, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo)) = v;
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = s1[tt][r], b = s2[tt][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          if (m == 0) { red[wave][(tt * 16 + gq * 4 + r) * 2] = a; red[wave][(tt * 16 + gq * 4 + r) * 2 + 1] = b; }
+        }
+      __syncthreads();
+      if (threadIdx.x < NT * 32) {
+        int co = ntile0 * 16 + (threadIdx.x >> 1);
+        if (co < g.CoutP) {
+          float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+          part[(((size_t)n * g.tiles + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
+        }
+      }
     }
   }
 }
@@ -374,7 +426,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_
 inline Bf16Cfg cfg_for(int c_out) {
   int ntiles = (c_out + 15) / 16;
   int nt = pick_nt(ntiles);
-  if (nt == 1) return {32, 32, 1, 16};
+  if (nt == 1) return {16, 32, 1, 8};
   if (nt == 2) return {16, 32, 2, 8};
   return {16, 16, 4, 4};
 }
@@ -417,9 +469,9 @@ int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hip
 
 const char* mc_bf16_kernel_name(const ConvGeom& g) {
   Bf16Cfg c = cfg_for(g.Cout);
-  if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,32,32,1,16,true>" : "k_conv_mfma_bf16<3,32,32,1,16,true>";
-  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,32,32,1,16>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,32,2,8>" : "k_conv_mfma_bf16<5,16,16,4,4>");
-  return c.nt == 1 ? "k_conv_mfma_bf16<3,32,32,1,16>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,32,2,8>" : "k_conv_mfma_bf16<3,16,16,4,4>");
+  if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,16,32,1,8,true>" : "k_conv_mfma_bf16<3,16,32,1,8,true>";
+  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,32,2,8>" : "k_conv_mfma_bf16<5,16,16,4,4>");
+  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,32,2,8>" : "k_conv_mfma_bf16<3,16,16,4,4>");
 }
 
 int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
@@ -427,17 +479,20 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
   Bf16Cfg c = cfg_for(g.Cout);
   int nt_total = (g.Cout + 15) / 16;
   int groups = (nt_total + c.nt - 1) / c.nt;
-  dim3 grid(g.tiles, groups, g.N);
+  int items = g.tiles * g.N;
+  int cap = 4096 / groups > 0 ? 4096 / groups : 1;     // persistent: a few resident workgroups per CU, several items each
+  int bx = items < cap ? items : cap;
+  dim3 grid(bx, groups, 1);
 #define LAUNCH(K, TH, TW, NT, MT)                                                                                    \
   hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT>), grid, dim3(256), 0, s, g, (const bf16_t*)x0,             \
                      (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups)
   if (g.out_f32) {
-    if (g.K == 5) hipLaunchKernelGGL((k_conv_mfma_bf16<5, 32, 32, 1, 16, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
-    else hipLaunchKernelGGL((k_conv_mfma_bf16<3, 32, 32, 1, 16, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
+    if (g.K == 5) hipLaunchKernelGGL((k_conv_mfma_bf16<5, 16, 32, 1, 8, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
+    else hipLaunchKernelGGL((k_conv_mfma_bf16<3, 16, 32, 1, 8, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
   } else if (g.K == 5) {
-    if (c.nt == 1) LAUNCH(5, 32, 32, 1, 16); else if (c.nt == 2) LAUNCH(5, 16, 32, 2, 8); else LAUNCH(5, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(5, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(5, 16, 32, 2, 8); else LAUNCH(5, 16, 16, 4, 4);
   } else if (g.K == 3) {
-    if (c.nt == 1) LAUNCH(3, 32, 32, 1, 16); else if (c.nt == 2) LAUNCH(3, 16, 32, 2, 8); else LAUNCH(3, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(3, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(3, 16, 32, 2, 8); else LAUNCH(3, 16, 16, 4, 4);
   } else {
     return MC_EUNSUPPORTED;
   }
