@@ -118,49 +118,70 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
   const ptrdiff_t x1_delta = x1 ? reinterpret_cast<const char*>(x1) - reinterpret_cast<const char*>(x0) : (ptrdiff_t)0;
 
   uint4 rin[IN_ITERS];
+  // static (stage-independent) part of this thread's staging slots: LDS slot, window row/col, channel block
+  int s_rc[IN_ITERS];                                            // bit 31: dead slot (tail iteration)
+#pragma unroll
+  for (int it = 0; it < IN_ITERS; ++it) {
+    int i = threadIdx.x + it * 256;
+    bool live = i < IN_ELEMS;
+    if (!live) i = IN_ELEMS - 1;
+    int cb = i / (TIH * TIW);
+    int rem = i - cb * (TIH * TIW);
+    int r = rem / TIW, c = rem - r * TIW;
+    s_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;   // cb in bit 30, r in bits 15..29, c in bits 0..14
+  }
   auto prefetch = [&](int t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
     const int wi = blockIdx.x + jitem * gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
-    // interior tile (uniform): the whole input window lies inside the image -> plain strided addressing
-    const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
+    // the two channel blocks of this chunk: base pointers and validity are wave-uniform (scalar)
+    const char* base[CHUNK_CB];
+    bool cbok[CHUNK_CB];
 #pragma unroll
-    for (int it = 0; it < IN_ITERS; ++it) {
-      int i = threadIdx.x + it * 256;
-      if (i >= IN_ELEMS) i = IN_ELEMS - 1;                      // duplicate (harmless) load for the tail
-      int cb = i / (TIH * TIW);
-      int rem = i - cb * (TIH * TIW);
-      int r = rem / TIW, c = rem - r * TIW;
+    for (int cb = 0; cb < CHUNK_CB; ++cb) {
       int gcb = ck * CHUNK_CB + cb;
+      cbok[cb] = gcb < g.CBin;
       int gcc = min(gcb, g.CBin - 1);
       bool second = gcc >= g.CB0;
       int scb = second ? gcc - g.CB0 : gcc;
       int sC8 = second ? g.CB1 : g.CB0;
-      const char* bp = reinterpret_cast<const char*>(x0) + (second ? x1_delta : (ptrdiff_t)0);
-      bool ok = gcb < g.CBin;
-      int sy, sx;
-      if (interior) {
-        sy = ty0 - g.pad + r; sx = tx0 - g.pad + c;
-      } else {
-        bool oky, okx;
-        sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
-        sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
-        ok = ok && oky && okx;
+      base[cb] = reinterpret_cast<const char*>(x0) + (second ? x1_delta : (ptrdiff_t)0) +
+                 cb8_index(n, scb, 0, 0, sC8, g.H, g.W) * sizeof(bf16_t);
+    }
+    // interior tile (uniform): the whole input window lies inside the image -> plain strided addressing
+    const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
+    if (interior) {
+      const int org = (ty0 - g.pad) * g.W + (tx0 - g.pad);
+#pragma unroll
+      for (int it = 0; it < IN_ITERS; ++it) {
+        int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
+        bool cb1 = ((s_rc[it] >> 30) & 1) != 0;
+        const char* bp = cb1 ? base[1] : base[0];
+        uint4 v = *reinterpret_cast<const uint4*>(bp + (size_t)(org + r * g.W + c) * 16);
+        rin[it] = (cb1 ? cbok[1] : cbok[0]) ? v : make_uint4(0, 0, 0, 0);
       }
-      uint4 v = *reinterpret_cast<const uint4*>(bp + cb8_index(n, scb, sy, sx, sC8, g.H, g.W) * sizeof(bf16_t));
-      rin[it] = ok ? v : make_uint4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < IN_ITERS; ++it) {
+        int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
+        bool cb1 = ((s_rc[it] >> 30) & 1) != 0;
+        const char* bp = cb1 ? base[1] : base[0];
+        bool oky, okx;
+        int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
+        int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
+        uint4 v = *reinterpret_cast<const uint4*>(bp + (size_t)(sy * g.W + sx) * 16);
+        rin[it] = ((cb1 ? cbok[1] : cbok[0]) && oky && okx) ? v : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < IN_ITERS; ++it) {
-      int i = threadIdx.x + it * 256;
-      if (i < IN_ELEMS) {
-        int cb = i / (TIH * TIW);
-        in_s[cb * PLANE + (i - cb * (TIH * TIW))] = rin[it];
+    for (int it = 0; it < IN_ITERS; ++it)
+      if (s_rc[it] >= 0) {
+        int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff, cb = (s_rc[it] >> 30) & 1;
+        in_s[cb * PLANE + r * TIW + c] = rin[it];
       }
-    }
   };
   // the bank slice changes only with the chunk: single-chunk layers (65 % of the FLOPs) stage it once
   auto stage_weights = [&](int ck) {
@@ -191,8 +212,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
       bv[tt][r] = (bias && co < g.Cout) ? bias[co] : 0.f;
     }
 
+  // cross-stage register prefetch only where the register budget allows it (single N-tile configuration);
+  // the wider configurations load and commit a stage back to back (their K loop is MT*NT MFMAs per fragment pair)
+  constexpr bool PREFETCH = (NT == 1);
   f32x4 acc[MT][NT];
-  if (total_stages > 0) prefetch(0);
+  if (PREFETCH && total_stages > 0) prefetch(0);
   for (int t = 0; t < total_stages; ++t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
     if (ck == 0) {
@@ -201,19 +225,23 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (!PREFETCH) prefetch(t);
     __syncthreads();                                            // LDS free: previous MFMA loop done
     commit();
     if (chunks > 1 || t == 0) stage_weights(ck);
     __syncthreads();
-    if (t + 1 < total_stages) prefetch(t + 1);                  // in flight during the MFMA loop
+    if (PREFETCH && t + 1 < total_stages) prefetch(t + 1);      // in flight during the MFMA loop
     // ---- MFMA loop (rolled over the K-steps: the per-lane operand offset is recomputed per step)
     const int wbase = (wave * MT / MTILES_X) * TIW + ((wave * MT) % MTILES_X) * 16 + m;
+    // this lane's (tap, channel-block) pair advances by 4 pairs = 2 taps per step: walk (ky, kx) incrementally
+    int kx = gq >> 1, ky = 0;                                   // pair jp = 4 s + gq -> tap = jp / 2, cb = jp % 2
+    const int cbk_off = (gq & 1) * PLANE + wbase;
 #pragma unroll 1
     for (int s = 0; s < STEPS; ++s) {
-      int jp = 4 * s + gq;
-      int tap = jp / CHUNK_CB, cbk = jp % CHUNK_CB;
-      if (tap >= K * K) tap = 0;                                // dummy pair: its weights are zero
-      const uint4* ap = in_s + (cbk * PLANE + (tap / K) * TIW + (tap % K) + wbase);
+      const bool dummy = ky >= K;                               // pairs past k*k: weights are zero, any valid address
+      const uint4* ap = in_s + (cbk_off + (dummy ? 0 : ky * TIW + kx));
+      kx += 2;
+      if (kx >= K) { kx -= K; ky += 1; }
       bf16x8 wf[NT];
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(s * NT + tt) * 64 + lane]);
@@ -236,34 +264,43 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1[tt][r] = 0.f; s2[tt][r] = 0.f; }
+    // output pointers of this lane's first M-tile per N-tile (bytes); later M-tiles are constant strides away
+    const int oy0 = ty0 + (wave * MT) / MTILES_X, ox0 = tx0 + ((wave * MT) % MTILES_X) * 16 + m;
+    char* dst0[NT];
+    bool cobok[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int cob = (ntile0 + tt) * 2 + (gq >> 1);            // C/D: row = 4*(lane>>4)+reg = output channel
+      cobok[tt] = cob < g.CBout;
+      const int cbc = min(cob, g.CBout - 1);
+      const int esz = OUT_F32 ? 4 : 2;
+      if (g.split8 > 0 && cbc >= g.split8)
+        dst0[tt] = reinterpret_cast<char*>(y1) + (cb8_index(n, cbc - g.split8, oy0, ox0, g.CBout - g.split8, g.Ho, g.Wo) + (gq & 1) * 4) * esz;
+      else
+        dst0[tt] = reinterpret_cast<char*>(y0) + (cb8_index(n, cbc, oy0, ox0, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo) + (gq & 1) * 4) * esz;
+    }
+    const size_t row_bytes = (size_t)g.Wo * 8 * (OUT_F32 ? 4 : 2);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int mt = wave * MT + i;
-      const int oy = ty0 + mt / MTILES_X, ox = tx0 + (mt % MTILES_X) * 16 + m;   // C/D: col = lane & 15 = pixel
+      const int oy = oy0 + i / MTILES_X, ox = ox0 + (i % MTILES_X) * 16;         // C/D: col = lane & 15 = pixel
       const bool inb = oy < g.Ho && ox < g.Wo;
+      const size_t off = (size_t)(i / MTILES_X) * row_bytes + (size_t)(i % MTILES_X) * 16 * 8 * (OUT_F32 ? 4 : 2);
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        const int cob = (ntile0 + tt) * 2 + (gq >> 1);          // C/D: row = 4*(lane>>4)+reg = output channel
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int co = (ntile0 + tt) * 16 + gq * 4 + r;
-          v[r] = co < g.Cout ? acc[i][tt][r] + bv[tt][r] : 0.f;
+          v[r] = acc[i][tt][r] + bv[tt][r];
           if (inb) { s1[tt][r] += v[r]; s2[tt][r] += v[r] * v[r]; }
         }
-        if (inb && cob < g.CBout) {
+        if (inb && cobok[tt]) {
           if (OUT_F32) {
-            float* yf = reinterpret_cast<float*>(y0);
-            *reinterpret_cast<float4*>(yf + cb8_index(n, cob, oy, ox, g.CBout, g.Ho, g.Wo) + (gq & 1) * 4) =
-                make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst0[tt] + off) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 pk;
             pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
             pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            bf16_t* dst = (g.split8 > 0 && cob >= g.split8)
-                              ? y1 + cb8_index(n, cob - g.split8, oy, ox, g.CBout - g.split8, g.Ho, g.Wo)
-                              : y0 + cb8_index(n, cob, oy, ox, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo);
-            *reinterpret_cast<uint2*>(dst + (gq & 1) * 4) = pk;
+            *reinterpret_cast<uint2*>(dst0[tt] + off) = pk;
           }
         }
       }
@@ -427,7 +464,7 @@ inline Bf16Cfg cfg_for(int c_out) {
   int ntiles = (c_out + 15) / 16;
   int nt = pick_nt(ntiles);
   if (nt == 1) return {16, 32, 1, 8};
-  if (nt == 2) return {16, 32, 2, 8};
+  if (nt == 2) return {16, 16, 2, 4};
   return {16, 16, 4, 4};
 }
 
@@ -470,8 +507,8 @@ int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hip
 const char* mc_bf16_kernel_name(const ConvGeom& g) {
   Bf16Cfg c = cfg_for(g.Cout);
   if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,16,32,1,8,true>" : "k_conv_mfma_bf16<3,16,32,1,8,true>";
-  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,32,2,8>" : "k_conv_mfma_bf16<5,16,16,4,4>");
-  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,32,2,8>" : "k_conv_mfma_bf16<3,16,16,4,4>");
+  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4>" : "k_conv_mfma_bf16<5,16,16,4,4>");
+  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4>" : "k_conv_mfma_bf16<3,16,16,4,4>");
 }
 
 int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
@@ -490,9 +527,9 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
     if (g.K == 5) hipLaunchKernelGGL((k_conv_mfma_bf16<5, 16, 32, 1, 8, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
     else hipLaunchKernelGGL((k_conv_mfma_bf16<3, 16, 32, 1, 8, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
   } else if (g.K == 5) {
-    if (c.nt == 1) LAUNCH(5, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(5, 16, 32, 2, 8); else LAUNCH(5, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(5, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4); else LAUNCH(5, 16, 16, 4, 4);
   } else if (g.K == 3) {
-    if (c.nt == 1) LAUNCH(3, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(3, 16, 32, 2, 8); else LAUNCH(3, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(3, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4); else LAUNCH(3, 16, 16, 4, 4);
   } else {
     return MC_EUNSUPPORTED;
   }
