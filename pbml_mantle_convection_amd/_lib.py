@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmantle_hip.so")
+LIB_PATH = os.environ.get("MANTLE_LIB", os.path.join(_HERE, "libmantle_hip.so"))
 
 MC_F32, MC_BF16 = 0, 1
 PAD_MODES = {"zeros": 0, "constant": 0, "replicate": 1, "reflect": 2}

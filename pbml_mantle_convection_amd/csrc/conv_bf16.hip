@@ -19,6 +19,7 @@
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -86,7 +87,10 @@ __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad,
 // epilogue therefore stores straight from registers (no LDS transpose, no extra barriers).
 // ------------------------------------------------------------------------------------------------
 template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false>
-__global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
+#ifndef MC_CONV_WAVES
+#define MC_CONV_WAVES 2
+#endif
+__global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_conv_mfma_bf16(
     ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ bank,
     const float* __restrict__ bias, bf16_t* __restrict__ y0, bf16_t* __restrict__ y1, float* __restrict__ part,
     int n_groups) {
@@ -115,73 +119,65 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
   const int items = g.N * g.tiles;
   const int my_items = (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total_stages = my_items * chunks;
-  const ptrdiff_t x1_delta = x1 ? reinterpret_cast<const char*>(x1) - reinterpret_cast<const char*>(x0) : (ptrdiff_t)0;
 
-  uint4 rin[IN_ITERS];
-  // static (stage-independent) part of this thread's staging slots: LDS slot, window row/col, channel block
-  int s_rc[IN_ITERS];                                            // bit 31: dead slot (tail iteration)
+  // Staging loads are raw buffer loads: one descriptor per (image, source tensor); an out-of-range offset
+  // returns zeros in hardware, which IS the zero padding / missing channel block — no branches, no selects,
+  // so the loads of a stage issue back to back.  Iterations are split per channel block (descriptor is uniform).
+  constexpr int PER_CB = (TIH * TIW + 255) / 256;
+  static_assert(IN_ITERS <= CHUNK_CB * PER_CB, "");
+  v4u rin[CHUNK_CB][PER_CB];
+  int s_rc[PER_CB];                                             // window (row, col) of this thread's slot; bit 31: dead
 #pragma unroll
-  for (int it = 0; it < IN_ITERS; ++it) {
+  for (int it = 0; it < PER_CB; ++it) {
     int i = threadIdx.x + it * 256;
-    bool live = i < IN_ELEMS;
-    if (!live) i = IN_ELEMS - 1;
-    int cb = i / (TIH * TIW);
-    int rem = i - cb * (TIH * TIW);
-    int r = rem / TIW, c = rem - r * TIW;
-    s_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;   // cb in bit 30, r in bits 15..29, c in bits 0..14
+    bool live = i < TIH * TIW;
+    if (!live) i = TIH * TIW - 1;
+    int r = i / TIW, c = i - r * TIW;
+    s_rc[it] = (live ? 0 : (1 << 31)) | (r << 15) | c;
   }
   auto prefetch = [&](int t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
     const int wi = blockIdx.x + jitem * gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
-    // the two channel blocks of this chunk: base pointers and validity are wave-uniform (scalar)
-    const char* base[CHUNK_CB];
-    bool cbok[CHUNK_CB];
+    const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
+    const int org = (ty0 - g.pad) * g.W + (tx0 - g.pad);
 #pragma unroll
     for (int cb = 0; cb < CHUNK_CB; ++cb) {
-      int gcb = ck * CHUNK_CB + cb;
-      cbok[cb] = gcb < g.CBin;
-      int gcc = min(gcb, g.CBin - 1);
-      bool second = gcc >= g.CB0;
-      int scb = second ? gcc - g.CB0 : gcc;
-      int sC8 = second ? g.CB1 : g.CB0;
-      base[cb] = reinterpret_cast<const char*>(x0) + (second ? x1_delta : (ptrdiff_t)0) +
-                 cb8_index(n, scb, 0, 0, sC8, g.H, g.W) * sizeof(bf16_t);
-    }
-    // interior tile (uniform): the whole input window lies inside the image -> plain strided addressing
-    const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
-    if (interior) {
-      const int org = (ty0 - g.pad) * g.W + (tx0 - g.pad);
+      const int gcb = ck * CHUNK_CB + cb;
+      const int gcc = min(gcb, g.CBin - 1);
+      const bool second = gcc >= g.CB0;
+      const int scb = second ? gcc - g.CB0 : gcc;
+      const int sC8 = second ? g.CB1 : g.CB0;
+      const size_t plane_bytes = (size_t)g.H * g.W * 16;
+      const char* pbase = reinterpret_cast<const char*>(second ? x1 : x0) + ((size_t)n * sC8 + scb) * plane_bytes;
+      // records = one channel-block plane; a missing block (gcb >= CBin) gets an empty descriptor -> all zeros
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, gcb < g.CBin ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll
-      for (int it = 0; it < IN_ITERS; ++it) {
+      for (int it = 0; it < PER_CB; ++it) {
         int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
-        bool cb1 = ((s_rc[it] >> 30) & 1) != 0;
-        const char* bp = cb1 ? base[1] : base[0];
-        uint4 v = *reinterpret_cast<const uint4*>(bp + (size_t)(org + r * g.W + c) * 16);
-        rin[it] = (cb1 ? cbok[1] : cbok[0]) ? v : make_uint4(0, 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < IN_ITERS; ++it) {
-        int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
-        bool cb1 = ((s_rc[it] >> 30) & 1) != 0;
-        const char* bp = cb1 ? base[1] : base[0];
-        bool oky, okx;
-        int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
-        int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
-        uint4 v = *reinterpret_cast<const uint4*>(bp + (size_t)(sy * g.W + sx) * 16);
-        rin[it] = ((cb1 ? cbok[1] : cbok[0]) && oky && okx) ? v : make_uint4(0, 0, 0, 0);
+        unsigned off;
+        if (interior) {
+          off = (unsigned)(org + r * g.W + c) * 16u;
+        } else {
+          bool oky, okx;
+          int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
+          int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
+          off = (oky && okx) ? (unsigned)(sy * g.W + sx) * 16u : 0xFFFFFFF0u;
+        }
+        rin[cb][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
       }
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < IN_ITERS; ++it)
-      if (s_rc[it] >= 0) {
-        int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff, cb = (s_rc[it] >> 30) & 1;
-        in_s[cb * PLANE + r * TIW + c] = rin[it];
-      }
+    for (int cb = 0; cb < CHUNK_CB; ++cb)
+#pragma unroll
+      for (int it = 0; it < PER_CB; ++it)
+        if (s_rc[it] >= 0) {
+          int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
+          in_s[cb * PLANE + r * TIW + c] = make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]);
+        }
   };
   // the bank slice changes only with the chunk: single-chunk layers (65 % of the FLOPs) stage it once
   auto stage_weights = [&](int ck) {
@@ -233,26 +229,49 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? 3 : 2)) void k_conv_mfma_bf16(
     if (PREFETCH && t + 1 < total_stages) prefetch(t + 1);      // in flight during the MFMA loop
     // ---- MFMA loop (rolled over the K-steps: the per-lane operand offset is recomputed per step)
     const int wbase = (wave * MT / MTILES_X) * TIW + ((wave * MT) % MTILES_X) * 16 + m;
-    // this lane's (tap, channel-block) pair advances by 4 pairs = 2 taps per step: walk (ky, kx) incrementally
+    // K loop, software pipelined: the fragments of step s+1 are read from LDS (MT + NT ds_read_b128 into their own
+    // registers) while the MT*NT MFMAs of step s issue, so an MFMA never waits on the LDS read issued just before it.
+    // This lane's (tap, channel-block) pair advances by 4 pairs = 2 taps per step: (ky, kx) is walked incrementally.
     int kx = gq >> 1, ky = 0;                                   // pair jp = 4 s + gq -> tap = jp / 2, cb = jp % 2
     const int cbk_off = (gq & 1) * PLANE + wbase;
-#pragma unroll 1
-    for (int s = 0; s < STEPS; ++s) {
+    auto load_frags = [&](int sidx, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
       const bool dummy = ky >= K;                               // pairs past k*k: weights are zero, any valid address
       const uint4* ap = in_s + (cbk_off + (dummy ? 0 : ky * TIW + kx));
       kx += 2;
       if (kx >= K) { kx -= K; ky += 1; }
-      bf16x8 wf[NT];
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(s * NT + tt) * 64 + lane]);
+      for (int tt = 0; tt < NT; ++tt) wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(sidx * NT + tt) * 64 + lane]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        // M-tile i of this wave sits (i / MTILES_X) rows and (i % MTILES_X) * 16 columns from the wave's first
-        bf16x8 xf = *reinterpret_cast<const bf16x8*>(ap + (i / MTILES_X) * TIW + (i % MTILES_X) * 16);
+      for (int i = 0; i < MT; ++i)
+        xf[i] = *reinterpret_cast<const bf16x8*>(ap + (i / MTILES_X) * TIW + (i % MTILES_X) * 16);
+    };
+    auto do_mfma = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt], xf, acc[i][tt], 0, 0, 0);
-      }
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt], xf[i], acc[i][tt], 0, 0, 0);
+    };
+#ifndef MC_KPIPE
+#define MC_KPIPE 0   /* A/B on MI355X: ping-pong fragment registers gave no gain (the level-0 layers sit at ~2.5 TB/s algorithmic) */
+#endif
+#if MC_KPIPE
+    bf16x8 xa[MT], xb[MT], wa[NT], wb[NT];
+    load_frags(0, xa, wa);
+#pragma unroll 1
+    for (int s = 0; s < STEPS; s += 2) {
+      if (s + 1 < STEPS) load_frags(s + 1, xb, wb);
+      do_mfma(xa, wa);
+      if (s + 2 < STEPS) load_frags(s + 2, xa, wa);
+      if (s + 1 < STEPS) do_mfma(xb, wb);
     }
+#else
+    bf16x8 xa[MT], wa[NT];
+#pragma unroll 1
+    for (int s = 0; s < STEPS; ++s) {
+      load_frags(s, xa, wa);
+      do_mfma(xa, wa);
+    }
+#endif
     if (ck != chunks - 1) continue;
 
     // ---- epilogue of this work item, straight from the accumulators
@@ -355,14 +374,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const short* base_lo) {
 constexpr int WTH = 16, WTW = 32;      // work-item tile (output pixels)
 
 template <int K, int NTW>
-__global__ __launch_bounds__(256) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
-                                                         const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
-                                                         float* __restrict__ part, int tiles_x, int tiles) {
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
+                                                            const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
+                                                            float* __restrict__ part, int tiles_x, int tiles) {
   constexpr int KK = K * K;
   constexpr int TIH = WTH + K - 1, TIW = WTW + K - 1;
   constexpr int XPS = ((TIH * TIW + 15) / 16) * 16 + 4;       // x plane stride (slots), == 4 mod 16
   constexpr int DPS = WTH * WTW + 4;                          // dy plane stride (slots)
   constexpr int NTAP = (KK + 3) / 4;                          // taps per wave (upper bound)
+  constexpr int X_ELEMS = 2 * TIH * TIW, X_ITERS = (X_ELEMS + 255) / 256;
+  constexpr int D_ELEMS = NTW * 2 * WTH * WTW, D_ITERS = D_ELEMS / 256;
+  static_assert(D_ELEMS % 256 == 0, "dy tile must divide evenly over the threads");
   __shared__ uint4 xs[2 * XPS];
   __shared__ uint4 ds[NTW * 2 * DPS];
   const int chunk = blockIdx.y, cog = blockIdx.z;
@@ -373,60 +395,119 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_
   const int lane_d = ((p >> 1) * DPS + 8 * gq + q) * 8 + (p & 1) * 4;
   const short* xs_s = reinterpret_cast<const short*>(xs);
   const short* ds_s = reinterpret_cast<const short*>(ds);
+  static_assert(3 + 4 * (NTAP - 1) >= KK, "wave 3 needs a free accumulator slot for the bias gradient");
+  const bool do_bias = (wave == 3) && (chunk == 0);
+  const bf16x8 ones = (bf16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const ptrdiff_t x1_delta = x1 ? reinterpret_cast<const char*>(x1) - reinterpret_cast<const char*>(x0) : (ptrdiff_t)0;
+
+  // this wave's taps -> short offsets into the x tile (static over the whole kernel)
+  int toff[NTAP];
+#pragma unroll
+  for (int ti = 0; ti < NTAP; ++ti) {
+    int tap = wave + 4 * ti;
+    toff[ti] = tap < KK ? ((tap / K) * TIW + (tap % K)) * 8 : -1;
+  }
+  // static staging slots of this thread
+  int x_rc[X_ITERS];
+#pragma unroll
+  for (int it = 0; it < X_ITERS; ++it) {
+    int i = threadIdx.x + it * 256;
+    bool live = i < X_ELEMS;
+    if (!live) i = X_ELEMS - 1;
+    int cb = i / (TIH * TIW);
+    int rem = i - cb * (TIH * TIW);
+    int r = rem / TIW, c = rem - r * TIW;
+    x_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;
+  }
+  // channel blocks of this (chunk): uniform
+  const char* xbase[2];
+  bool xok[2];
+  int xC8[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    int gcb = chunk * 2 + cb;
+    xok[cb] = gcb < g.CBin;
+    int gcc = min(gcb, g.CBin - 1);
+    bool second = gcc >= g.CB0;
+    xC8[cb] = second ? g.CB1 : g.CB0;
+    xbase[cb] = reinterpret_cast<const char*>(x0) + (second ? x1_delta : (ptrdiff_t)0) +
+                cb8_index(0, second ? gcc - g.CB0 : gcc, 0, 0, xC8[cb], g.H, g.W) * sizeof(bf16_t);
+  }
+
+  uint4 rx[X_ITERS], rd[D_ITERS];
+  auto prefetch = [&](int wi) {
+    const int n = wi / tiles, tile = wi - n * tiles;
+    const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
+    const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
+#pragma unroll
+    for (int it = 0; it < X_ITERS; ++it) {
+      int r = (x_rc[it] >> 15) & 0x7fff, c = x_rc[it] & 0x7fff;
+      bool cb1 = ((x_rc[it] >> 30) & 1) != 0;
+      const char* bp = (cb1 ? xbase[1] : xbase[0]) + (size_t)n * (cb1 ? xC8[1] : xC8[0]) * g.H * g.W * 16;
+      bool ok = cb1 ? xok[1] : xok[0];
+      int sy, sx;
+      if (interior) { sy = ty0 - g.pad + r; sx = tx0 - g.pad + c; }
+      else {
+        bool oky, okx;
+        sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
+        sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
+        ok = ok && oky && okx;
+      }
+      uint4 v = *reinterpret_cast<const uint4*>(bp + (size_t)(sy * g.W + sx) * 16);
+      rx[it] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < D_ITERS; ++it) {
+      int i = threadIdx.x + it * 256;
+      int pl = i / (WTH * WTW);                     // plane = co-tile * 2 + half
+      int rem = i - pl * (WTH * WTW);
+      int r = rem / WTW, c = rem - r * WTW;
+      int cob = (cog * NTW) * 2 + pl;
+      int oy = ty0 + r, ox = tx0 + c;
+      bool ok = cob < g.CBout && oy < g.Ho && ox < g.Wo;
+      uint4 v = *reinterpret_cast<const uint4*>(dy + cb8_index(n, min(cob, g.CBout - 1), min(oy, g.Ho - 1), min(ox, g.Wo - 1),
+                                                               g.CBout, g.Ho, g.Wo));
+      rd[it] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < X_ITERS; ++it)
+      if (x_rc[it] >= 0) {
+        int r = (x_rc[it] >> 15) & 0x7fff, c = x_rc[it] & 0x7fff, cb = (x_rc[it] >> 30) & 1;
+        xs[cb * XPS + r * TIW + c] = rx[it];
+      }
+#pragma unroll
+    for (int it = 0; it < D_ITERS; ++it) {
+      int i = threadIdx.x + it * 256;
+      int pl = i / (WTH * WTW);
+      ds[pl * DPS + (i - pl * (WTH * WTW))] = rd[it];
+    }
+  };
 
   f32x4 acc[NTAP][NTW];
 #pragma unroll
   for (int a = 0; a < NTAP; ++a)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  static_assert(3 + 4 * (NTAP - 1) >= KK, "wave 3 needs a free accumulator slot for the bias gradient");
-  const bool do_bias = (wave == 3) && (chunk == 0);
-  const bf16x8 ones = (bf16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   const int work = g.N * tiles;
+  if ((int)blockIdx.x < work) prefetch(blockIdx.x);
   for (int wi = blockIdx.x; wi < work; wi += gridDim.x) {
-    const int n = wi / tiles, tile = wi % tiles;
-    const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * TIH * TIW; i += 256) {
-      int cb = i / (TIH * TIW);
-      int rem = i - cb * (TIH * TIW);
-      int r = rem / TIW, c = rem - r * TIW;
-      int gcb = chunk * 2 + cb;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (gcb < g.CBin) {
-        int sy = pad_map(ty0 + r - g.pad, g.H, g.pad_mode), sx = pad_map(tx0 + c - g.pad, g.W, g.pad_mode);
-        if (sy >= 0 && sx >= 0) {
-          const bf16_t* src = gcb < g.CB0 ? x0 : x1;
-          int scb = gcb < g.CB0 ? gcb : gcb - g.CB0;
-          int sC8 = gcb < g.CB0 ? g.CB0 : g.CB1;
-          v = *reinterpret_cast<const uint4*>(src + cb8_index(n, scb, sy, sx, sC8, g.H, g.W));
-        }
-      }
-      xs[cb * XPS + rem] = v;
-    }
-    for (int i = threadIdx.x; i < NTW * 2 * WTH * WTW; i += 256) {
-      int pl = i / (WTH * WTW);                     // plane = co-tile * 2 + half
-      int rem = i - pl * (WTH * WTW);
-      int r = rem / WTW, c = rem - r * WTW;
-      int cob = (cog * NTW) * 2 + pl;
-      int oy = ty0 + r, ox = tx0 + c;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (cob < g.CBout && oy < g.Ho && ox < g.Wo)
-        v = *reinterpret_cast<const uint4*>(dy + cb8_index(n, cob, oy, ox, g.CBout, g.Ho, g.Wo));
-      ds[pl * DPS + rem] = v;
-    }
+    commit();
     __syncthreads();
+    if (wi + (int)gridDim.x < work) prefetch(wi + gridDim.x);   // next work item's loads retire under the MFMA loop
+#pragma unroll 1
     for (int row = 0; row < WTH; ++row) {
       bf16x8 a[NTW];
 #pragma unroll
       for (int t = 0; t < NTW; ++t) a[t] = tr_frag(ds_s + (t * 2 * DPS + row * WTW) * 8 + lane_d);
+      const short* xrow = xs_s + row * TIW * 8 + lane_x;
 #pragma unroll
       for (int ti = 0; ti < NTAP; ++ti) {
-        int tap = wave + 4 * ti;
-        if (tap < KK) {
-          int ky = tap / K, kx = tap % K;
-          bf16x8 b = tr_frag(xs_s + ((row + ky) * TIW + kx) * 8 + lane_x);
+        if (toff[ti] >= 0) {
+          bf16x8 b = tr_frag(xrow + toff[ti]);
 #pragma unroll
           for (int t = 0; t < NTW; ++t) acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[ti][t], 0, 0, 0);
         }

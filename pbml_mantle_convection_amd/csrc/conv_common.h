@@ -52,7 +52,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
     int ntiles = (g.Cout + 15) / 16;
     int ntw = (ntiles % 2 == 0) ? 2 : 1;
     long other = (long)((g.CBin + 1) / 2) * ((ntiles + ntw - 1) / ntw);
-    G = (1024 + other - 1) / other;
+    G = (768 + other - 1) / other;
     if (G < 32) G = 32;
     work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
   } else {

@@ -81,15 +81,21 @@ __global__ void k_pack_grad_nchw(const float* __restrict__ g, int N, int C, int 
   }
 }
 
+__global__ void k_zero_f32(float* __restrict__ p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 __global__ void k_sum_hw(const float* __restrict__ x, int hw, float scale, float* __restrict__ out) {
-  const float* p = x + (size_t)blockIdx.x * hw;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < hw; i += blockDim.x) s += (double)p[i];
-  s = wave_sum_d(s);
-  __shared__ double red[4];
+  // grid (chunks, nc): each block reduces a slice of one plane and adds it to out[nc] (zeroed by the caller)
+  const float* p = x + (size_t)blockIdx.y * hw;
+  float s = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) s += p[i];
+  s = wave_sum(s);
+  __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)scale);
+  if (threadIdx.x == 0) atomicAdd(out + blockIdx.y, ((red[0] + red[1]) + (red[2] + red[3])) * scale);
 }
 
 // =================================================================================================
@@ -403,7 +409,7 @@ __global__ void k_bicubic_fwd(const T* __restrict__ x, int C8, int Hi, int Wi, i
 // adjoint of the bicubic upsample.  One block = an 8 x 8 tile of input (low-res) pixels of one channel block:
 // the (folded) output-gradient window the tile touches is staged in LDS once (the transposed tap lists of 8
 // consecutive input pixels cover <= WIN consecutive output pixels), then each thread gathers its pixel from LDS.
-constexpr int BT = 8, BWIN = 40;
+constexpr int BT = 16, BWIN = 40;
 template <typename T>
 __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int Hi, int Wi, const int* __restrict__ tys,
                                                      const int* __restrict__ tyj, const float* __restrict__ tyw,
@@ -437,12 +443,12 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
     }
   }
   __syncthreads();
-  const int ly = threadIdx.x / (BT * 4), lx = (threadIdx.x / 4) % BT, part = threadIdx.x & 3;   // 4 threads per pixel
+  const int ly = threadIdx.x / BT, lx = threadIdx.x % BT, part = 0;                            // one thread per pixel
   const int yi = ty0 + ly, xi = tx0 + lx;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (yi < ty1 && xi < tx1) {
     int a0 = tys[yi], a1 = tys[yi + 1];
-    for (int a = a0 + part; a < a1; a += 4) {
+    for (int a = a0 + part; a < a1; ++a) {
       int yo = tyj[a];
       float wa = tyw[a];
       for (int b = txs[xi]; b < txs[xi + 1]; ++b) {
@@ -460,11 +466,6 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
         for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
       }
     }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    acc[j] += __shfl_xor(acc[j], 1, 64);
-    acc[j] += __shfl_xor(acc[j], 2, 64);
   }
   if (part == 0 && yi < ty1 && xi < tx1) V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
 }
@@ -637,7 +638,10 @@ int mc_pack_grad_nchw(const float* g, int32_t n, int32_t c, int32_t h, int32_t w
 
 int mc_sum_hw(const float* x, int32_t nc, int32_t hw, float scale, float* out, void* stream) {
   if (!x || !out || nc <= 0 || hw <= 0) return MC_EINVAL;
-  hipLaunchKernelGGL(k_sum_hw, dim3(nc), dim3(256), 0, (hipStream_t)stream, x, hw, scale, out);
+  hipLaunchKernelGGL(k_zero_f32, dim3(cdiv(nc, 256)), dim3(256), 0, (hipStream_t)stream, out, nc);
+  int chunks = cdiv(hw, 256 * 16);
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(k_sum_hw, dim3(chunks, nc), dim3(256), 0, (hipStream_t)stream, x, hw, scale, out);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
