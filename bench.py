@@ -63,6 +63,19 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MANTLE_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(kernel, B, H, W, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/round1_pmc_traffic.json, collected on this same workload); None for any other workload."""
+    if (B, H, W, precision) != (32, 506, 506, "bf16"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(kernel.replace(" ", ""))
+        return None if k is None else k["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, H, W):
     """The CPU oracle (oracle/ref_cpu.py, pinned against the reference by golden vectors) timed on the
     host cores: same network, same loss (incl. momentum term), fp32, bounded sample."""
@@ -157,6 +170,7 @@ def main():
     torch.cuda.synchronize(dev)
     roof = eng.probe_summary(probe, HBM_PEAK_GBS)
     eng.disable_probe()
+    roof["traffic"] = pmc_traffic(roof["kernel"], B, H, W, args.precision)
 
     line = None
     if rank == 0:

@@ -588,8 +588,8 @@ int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hip
 const char* mc_bf16_kernel_name(const ConvGeom& g) {
   Bf16Cfg c = cfg_for(g.Cout);
   if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,16,32,1,8,true>" : "k_conv_mfma_bf16<3,16,32,1,8,true>";
-  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4>" : "k_conv_mfma_bf16<5,16,16,4,4>");
-  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4>" : "k_conv_mfma_bf16<3,16,16,4,4>");
+  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4,false>" : "k_conv_mfma_bf16<5,16,16,4,4,false>");
+  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4,false>" : "k_conv_mfma_bf16<3,16,16,4,4,false>");
 }
 
 int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,

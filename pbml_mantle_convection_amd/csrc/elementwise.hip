@@ -421,13 +421,10 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
   const int ty0 = (blockIdx.x / tiles_x) * BT, tx0 = (blockIdx.x % tiles_x) * BT;
   const int ty1 = min(ty0 + BT, Hi), tx1 = min(tx0 + BT, Wi);
   if (threadIdx.x == 0) {
-    // output ranges referenced by this tile (tap lists are sorted by output index)
-    int ylo = 1 << 30, yhi = -1, xlo = 1 << 30, xhi = -1;
-    for (int i = ty0; i < ty1; ++i)
-      if (tys[i + 1] > tys[i]) { ylo = min(ylo, tyj[tys[i]]); yhi = max(yhi, tyj[tys[i + 1] - 1]); }
-    for (int i = tx0; i < tx1; ++i)
-      if (txs[i + 1] > txs[i]) { xlo = min(xlo, txj[txs[i]]); xhi = max(xhi, txj[txs[i + 1] - 1]); }
-    lim[0] = ylo; lim[1] = yhi; lim[2] = xlo; lim[3] = xhi;
+    // output ranges referenced by this tile: the transposed tap lists are sorted by output index and monotone in the
+    // input index, so the range is [first entry of the first row's list, last entry of the last row's list]
+    lim[0] = tyj[tys[ty0]]; lim[1] = tyj[tys[ty1] - 1];
+    lim[2] = txj[txs[tx0]]; lim[3] = txj[txs[tx1] - 1];
   }
   __syncthreads();
   const int ylo = lim[0], yhi = lim[1], xlo = lim[2], xhi = lim[3];
@@ -447,23 +444,41 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
   const int yi = ty0 + ly, xi = tx0 + lx;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (yi < ty1 && xi < tx1) {
+    // this pixel's x tap list in registers (<= BXT entries; longer lists - image borders of large scale factors -
+    // take the slow path below)
+    constexpr int BXT = 12;
+    const int b0 = txs[xi], nb = txs[xi + 1] - b0;
+    int xj[BXT];
+    float xw[BXT];
+#pragma unroll
+    for (int k = 0; k < BXT; ++k) {
+      xj[k] = k < nb ? txj[b0 + k] : 0;
+      xw[k] = k < nb ? txw[b0 + k] : 0.f;
+    }
+    const bool fast = fits && nb <= BXT;
     int a0 = tys[yi], a1 = tys[yi + 1];
     for (int a = a0 + part; a < a1; ++a) {
       int yo = tyj[a];
       float wa = tyw[a];
-      for (int b = txs[xi]; b < txs[xi + 1]; ++b) {
-        float w = wa * txw[b];
-        float v[8];
-        if (fits) {
+      if (fast) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = win[yo - ylo][txj[b] - xlo][j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
-          grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
+        for (int k = 0; k < BXT; ++k) {
+          if (k < nb) {
+            float w = wa * xw[k];
+            const float4* wp = reinterpret_cast<const float4*>(win[yo - ylo][xj[k] - xlo]);
+            float4 p0 = wp[0], p1 = wp[1];
+            acc[0] += w * p0.x; acc[1] += w * p0.y; acc[2] += w * p0.z; acc[3] += w * p0.w;
+            acc[4] += w * p1.x; acc[5] += w * p1.y; acc[6] += w * p1.z; acc[7] += w * p1.w;
+          }
         }
+      } else {
+        for (int b = b0; b < b0 + nb; ++b) {
+          float w = wa * txw[b];
+          float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+          for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+        }
       }
     }
   }

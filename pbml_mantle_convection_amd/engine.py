@@ -13,6 +13,7 @@ ConvAE.forward (.ipynb_checkpoints/pycold-checkpoint.py:1094-1115), FluidLayer.f
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -264,6 +265,7 @@ class Engine:
         self.mc_dtype, self.t_dtype = DTYPES[precision]
         self.shape = None
         self._tables = {}
+        self.overlap_wgrad = os.environ.get("MANTLE_OVERLAP_WGRAD", "0") != "0"   # A/B on MI355X: no gain, every kernel already fills the chip
 
     # -------------------------------------------------------------- planning
     def configure(self, N: int, H: int, W: int, device):
@@ -350,8 +352,12 @@ class Engine:
             max_wg = max(max_wg, L.call("mc_wgrad_partial_bytes", C.byref(d)))
             self.plan.append(e)
         self.T = T
-        self.dY = torch.empty(max_dy, dtype=self.t_dtype, device=device)
+        # two dY buffers: the filter gradient of layer L runs on a side stream while the main stream already
+        # prepares dY of layer L-1 (see backward)
+        self.dYs = [torch.empty(max_dy, dtype=self.t_dtype, device=device) for _ in range(2)]
+        self.dY = self.dYs[0]
         self.wg_part = torch.empty(max_wg, dtype=torch.uint8, device=device)
+        self.side = torch.cuda.Stream(device=device)
         last = self.plan[-1]
         assert last["node"].kind == "conv", "graph must end in a conv node"
         self.final_plain = last["node"].post == L.POST_NONE
@@ -443,13 +449,21 @@ class Engine:
         act = L.ACTS[g.act]
         for t in T.values():
             t.gsrcs = []
+        # Two-stream backward: the filter-gradient kernels (x, dY -> dW) of a layer depend only on that layer's dY,
+        # so they run on `side` while `main` continues with the input gradient and the next layer's GroupNorm
+        # backward.  dY alternates between two buffers; main waits for the side stream before reusing one.
+        main = torch.cuda.current_stream()
+        side = self.side if self.overlap_wgrad else main
+        side.wait_stream(main)
+        wg_done = [None, None]
+        k = 0
         fo = T[self.plan[-1]["node"].out]
         mean = None
         if g.subtract_mean:
             L.call("mc_sum_hw", L.ptr(gout), N * g.c_out, self.out_h * self.out_w, 1.0 / (fo.H * fo.W),
                    L.ptr(self.gmean), st)
             mean = self.gmean
-        gdst = self.dY if self.final_plain else self.dOut
+        gdst = self.dYs[0] if self.final_plain else self.dOut
         L.call("mc_pack_grad_nchw", L.ptr(gout), N, g.c_out, fo.H, fo.W, g.crop_w, L.ptr(mean), self.mc_dtype,
                L.ptr(gdst), st)
         if not self.final_plain:
@@ -467,7 +481,9 @@ class Engine:
             d = e["desc"]
             o = T[node.out]
             srcs = [T[i] for i in node.srcs]
-            dY = self.dY
+            dY = self.dYs[k & 1]
+            if wg_done[k & 1] is not None:
+                main.wait_event(wg_done[k & 1])          # the side stream has finished reading this dY buffer
             if node.post != L.POST_NONE:
                 gs = list(o.gsrcs)
                 if node.pool > 1:
@@ -492,9 +508,19 @@ class Engine:
                        self.mc_dtype, g0, g1, L.ptr(dY), st)
             x0 = L.ptr(srcs[0].buf)
             x1 = L.ptr(srcs[1].buf) if len(srcs) > 1 else None
-            L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(self.wg_part), st)
-            L.call("mc_conv2d_wgrad_finalize", C.byref(d), L.ptr(self.wg_part), L.ptr(grads[node.name + "weight"]),
-                   L.ptr(grads[node.name + "bias"]), st)
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(main)                           # dY of this layer is complete
+                side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ss = L.stream()
+                L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(self.wg_part), ss)
+                L.call("mc_conv2d_wgrad_finalize", C.byref(d), L.ptr(self.wg_part), L.ptr(grads[node.name + "weight"]),
+                       L.ptr(grads[node.name + "bias"]), ss)
+                if side is not main:
+                    wg_done[k & 1] = torch.cuda.Event()
+                    wg_done[k & 1].record(side)
+            k += 1
             if e["need_dgrad"]:
                 w = self._param(params, node.name + "weight")
                 L.call("mc_pack_weights", C.byref(d), L.ptr(w), 1, L.ptr(e["dbank"]), st)
@@ -508,6 +534,7 @@ class Engine:
                         # adjoint of the padding: fold the halo onto the interior once, consumers read at an offset
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
+        main.wait_stream(side)
 
     # -------------------------------------------------------------- measurement hooks (bench.py)
     _probe = None
