@@ -125,6 +125,13 @@ int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const
                     void* partials, void* stream);
 int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float* dw_unique,
                              float* dbias, void* stream);
+/* Batched forms (one launch for many layers; per-layer tables are plain host arrays of length n):
+ * the per-step bank packing and the filter-gradient combine are tiny per layer and latency-bound when
+ * launched one layer at a time. */
+int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_unique, const int32_t* dgrad,
+                            void* const* packed, int32_t n, void* stream);
+int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* const* partials, float* const* dw_unique,
+                                     float* const* dbias, int32_t n, void* stream);
 
 /* Adjoint of F.pad(mode) on a padded-domain gradient (output of mc_conv2d in input-gradient mode):
  * adds the halo of buf [n][c8][hs+2p][ws+2p][8] onto the interior positions it was padded from
@@ -158,6 +165,12 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
                         const float* stats_ng2, const float* m12_ng2, const float* gamma,
                         const float* beta, int32_t post, int32_t act, int32_t dtype,
                         const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream);
+/* Phases 2 + 3 in one launch: every workgroup re-derives its groups' (m1, m2) from the phase-1 partials
+ * (blocks x channels, L2-resident) and the first workgroup of each (n, channel block) accumulates dgamma/dbeta. */
+int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                              const float* stats_ng2, const float* partials, int32_t blocks, const float* gamma,
+                              const float* beta, int32_t act, int32_t dtype, const mc_grad_src* g0,
+                              const mc_grad_src* g1, float* dgamma, float* dbeta, void* dy, void* stream);
 
 /* ---- resampling (nn.AvgPool2d, nn.Upsample(mode='bicubic'); Unet :2002,2009,2014; ConvAE :1051,1079) */
 int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t f, int32_t dtype,

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mc_wgrad_partial_bytes": (_sz, [_CD]),
     "mc_conv2d_wgrad": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp]),
     "mc_conv2d_wgrad_finalize": (C.c_int, [_CD, _vp, _vp, _vp, _vp]),
+    "mc_pack_weights_batched": (C.c_int, [_CD, _vp, _vp, _vp, _i32, _vp]),
+    "mc_conv2d_wgrad_finalize_batched": (C.c_int, [_CD, _vp, _vp, _vp, _i32, _vp]),
     "mc_fold_padded": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
@@ -65,6 +67,8 @@ SIGNATURES = {
     "mc_gn_act_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mc_gn_act_bwd_apply": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _GS, _GS, _vp, _vp]),
+    "mc_gn_act_bwd_apply_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
+                                            _GS, _GS, _vp, _vp, _vp, _vp]),
     "mc_avgpool_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_bicubic_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mc_bicubic_bwd": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,

@@ -12,6 +12,7 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
                    void* y1, float* part, hipStream_t s);
 int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s);
 const char* mc_bf16_kernel_name(const ConvGeom& g);
+void mc_bf16_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles);
 
 namespace {
 
@@ -28,64 +29,53 @@ int geom_for(const mc_conv_desc* d, ConvGeom& g) {
 }
 
 // f32 bank: [cbin][tap][ci8][CoutP]
-__global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, float* __restrict__ bank) {
-  const int K = g.K, KK = K * K;
-  if (!dgrad) {
-    size_t total = (size_t)g.CBin * KK * 8 * g.CoutP;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-      int co = (int)(i % g.CoutP);
-      size_t r = i / g.CoutP;
-      int j = (int)(r % 8); r /= 8;
-      int tap = (int)(r % KK);
-      int cb = (int)(r / KK);
-      int ci = cb < g.CB0 ? cb * 8 + j : g.Cin0 + (cb - g.CB0) * 8 + j;
-      bool ok = (cb < g.CB0 ? (cb * 8 + j < g.Cin0) : ((cb - g.CB0) * 8 + j < g.Cin1)) && co < g.Cout;
-      float v = 0.f;
-      if (ok) {
-        int ky = tap / K, kx = tap % K;
-        int u = co, kxs = kx;
-        if (co >= g.U) { u = co - g.U; kxs = K - 1 - kx; }   // x-mirrored copy (symmetric_layers_torch.py:121-123)
-        v = wu[(((size_t)u * g.Cin + ci) * K + ky) * K + kxs];
-      }
-      bank[i] = v;
-    }
-  } else {
-    // dgrad conv: in-channels = forward c_out, out-channels = forward (padded) c_in, rotated taps
-    const int CBd = g.CBout, CoP = g.CinP;
-    size_t total = (size_t)CBd * KK * 8 * CoP;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-      int o = (int)(i % CoP);
-      size_t r = i / CoP;
-      int j = (int)(r % 8); r /= 8;
-      int tap = (int)(r % KK);
-      int cb = (int)(r / KK);
-      int co = cb * 8 + j;                 // forward output channel
-      int ob = o / 8, oj = o % 8;          // forward input channel (padded index)
-      int ci = ob < g.CB0 ? ob * 8 + oj : g.Cin0 + (ob - g.CB0) * 8 + oj;
-      bool ok = (ob < g.CB0 ? (ob * 8 + oj < g.Cin0) : ((ob - g.CB0) * 8 + oj < g.Cin1)) && co < g.Cout;
-      float v = 0.f;
-      if (ok) {
-        int ky = K - 1 - tap / K, kx = K - 1 - tap % K;
-        int u = co, kxs = kx;
-        if (co >= g.U) { u = co - g.U; kxs = K - 1 - kx; }
-        v = wu[(((size_t)u * g.Cin + ci) * K + ky) * K + kxs];
-      }
-      bank[i] = v;
-    }
+__global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, float* __restrict__ bank, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    bank[i] = pack_value_f32(g, wu, i, dgrad);
+}
+
+// ---- batched packing: the job table travels by value in the kernel arguments (<= PK_MAX jobs per launch)
+struct PkJob {
+  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP;
+  int dgrad, steps, ntiles, bf16, first_block;
+  unsigned total;
+  const float* w;
+  void* out;
+};
+constexpr int PK_MAX = 24;
+struct PkTable { int n; PkJob j[PK_MAX]; };
+
+__global__ void k_pack_batched(PkTable t) {
+  int ji = 0;
+#pragma unroll 1
+  for (int k = 1; k < t.n; ++k) if ((int)blockIdx.x >= t.j[k].first_block) ji = k;
+  const PkJob& job = t.j[ji];
+  const int nblk = (ji + 1 < t.n ? t.j[ji + 1].first_block : (int)gridDim.x) - job.first_block;
+  for (size_t i = (size_t)(blockIdx.x - job.first_block) * blockDim.x + threadIdx.x; i < job.total; i += (size_t)nblk * blockDim.x) {
+    if (job.bf16) reinterpret_cast<bf16_t*>(job.out)[i] = f2bf(pack_value_bf16(job, job.w, i, job.dgrad, job.steps, job.ntiles));
+    else reinterpret_cast<float*>(job.out)[i] = pack_value_f32(job, job.w, i, job.dgrad);
   }
 }
 
 // dW_unique[u][ci][ky][kx] += sum_G part[G][u][...] + (u < h/2) sum_G part[G][U+u][..][ky][K-1-kx]
 // 64 outputs per block; the four waves split the slab range and combine through LDS (deterministic order)
-__global__ __launch_bounds__(256) void k_wgrad_finalize(ConvGeom g, const float* __restrict__ part,
-                                                        float* __restrict__ dw, float* __restrict__ db) {
+struct WfJob {
+  int K, U, Cin, Cin0, CB0, CinP, CoutP, Cout, symh, G, first_block;
+  const float* part;
+  float* dw;
+  float* db;
+};
+constexpr int WF_MAX = 32;
+struct WfTable { int n; WfJob j[WF_MAX]; };
+
+__device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock) {
   const int K = g.K, KK = K * K;
   const int cols = g.CinP * KK + 1;
   const size_t slab = (size_t)g.CoutP * cols;
   const size_t nW = (size_t)g.U * g.Cin * KK;
   const size_t total = nW + g.Cout;
   const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const size_t i = (size_t)blockIdx.x * 64 + e;
+  const size_t i = (size_t)lblock * 64 + e;
   __shared__ float red[4][64];
   float s = 0.f;
   if (i < total) {
@@ -99,13 +89,14 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(ConvGeom g, const float*
       int u = (int)(r / g.Cin);
       int cip = cin_padded_index(ci, g.Cin0, g.CB0);
       o1 = (size_t)u * cols + (size_t)cip * KK + ky * K + kx;
-      if (u < g.sym_h / 2) { two = true; o2 = (size_t)(g.U + u) * cols + (size_t)cip * KK + ky * K + (K - 1 - kx); }
+      if (u < g.symh / 2) { two = true; o2 = (size_t)(g.U + u) * cols + (size_t)cip * KK + ky * K + (K - 1 - kx); }
     } else {
       o1 = (size_t)(i - nW) * cols + (size_t)g.CinP * KK;
     }
+    const float* part = g.part;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int G = w;
-    for (; G + 12 < g.wgrad_G; G += 16) {
+    for (; G + 12 < g.G; G += 16) {
       a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + 4) * slab + o1];
       a2 += part[(size_t)(G + 8) * slab + o1]; a3 += part[(size_t)(G + 12) * slab + o1];
       if (two) {
@@ -113,7 +104,7 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(ConvGeom g, const float*
         a2 += part[(size_t)(G + 8) * slab + o2]; a3 += part[(size_t)(G + 12) * slab + o2];
       }
     }
-    for (; G < g.wgrad_G; G += 4) {
+    for (; G < g.G; G += 4) {
       a0 += part[(size_t)G * slab + o1];
       if (two) a0 += part[(size_t)G * slab + o2];
     }
@@ -123,9 +114,28 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(ConvGeom g, const float*
   __syncthreads();
   if (w == 0 && i < total) {
     float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    if (i < nW) { if (dw) dw[i] += r; }
-    else if (db) db[i - nW] += r;
+    if (i < nW) { if (g.dw) g.dw[i] += r; }
+    else if (g.db) g.db[i - nW] += r;
   }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_finalize(WfTable t) {
+  int ji = 0;
+#pragma unroll 1
+  for (int k = 1; k < t.n; ++k) if ((int)blockIdx.x >= t.j[k].first_block) ji = k;
+  wgrad_finalize_block(t.j[ji], blockIdx.x - t.j[ji].first_block);
+}
+
+int wf_fill(const mc_conv_desc* d, const void* partials, float* dw, float* db, WfJob& j, int& blocks) {
+  ConvGeom g;
+  int rc = geom_for(d, g);
+  if (rc) return rc;
+  if (!partials || (!dw && !db)) return MC_EINVAL;
+  j.K = g.K; j.U = g.U; j.Cin = g.Cin; j.Cin0 = g.Cin0; j.CB0 = g.CB0; j.CinP = g.CinP; j.CoutP = g.CoutP; j.Cout = g.Cout;
+  j.symh = g.sym_h; j.G = g.wgrad_G; j.part = (const float*)partials; j.dw = dw; j.db = db;
+  size_t total = (size_t)g.U * g.Cin * g.K * g.K + g.Cout;
+  blocks = (int)((total + 63) / 64);
+  return MC_OK;
 }
 
 }  // namespace
@@ -161,7 +171,7 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
   size_t total = mc_packed_weight_bytes(d, dgrad) / sizeof(float);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_pack_f32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, w_unique, dgrad, (float*)packed);
+  hipLaunchKernelGGL(k_pack_f32, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, w_unique, dgrad, (float*)packed, total);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -205,17 +215,65 @@ int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const
   return mc_wgrad_f32(g, x0, x1, dy, partials, (hipStream_t)stream);
 }
 
+int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* const* partials, float* const* dw,
+                                     float* const* db, int32_t n, void* stream) {
+  if (!descs || !partials || !dw || !db || n <= 0) return MC_EINVAL;
+  for (int base = 0; base < n; base += WF_MAX) {
+    WfTable t;
+    t.n = n - base < WF_MAX ? n - base : WF_MAX;
+    int blocks = 0;
+    for (int k = 0; k < t.n; ++k) {
+      int b = 0;
+      int rc = wf_fill(&descs[base + k], partials[base + k], dw[base + k], db[base + k], t.j[k], b);
+      if (rc) return rc;
+      t.j[k].first_block = blocks;
+      blocks += b;
+    }
+    hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    MC_CHECK_LAUNCH();
+  }
+  return MC_OK;
+}
+
 int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float* dw_unique, float* dbias,
                              void* stream) {
-  ConvGeom g;
-  int rc = geom_for(d, g);
-  if (rc) return rc;
-  if (!partials || (!dw_unique && !dbias)) return MC_EINVAL;
-  size_t total = (size_t)g.U * g.Cin * g.K * g.K + g.Cout;
-  int blocks = (int)((total + 63) / 64);
-  hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (const float*)partials,
-                     dw_unique, dbias);
-  MC_CHECK_LAUNCH();
+  return mc_conv2d_wgrad_finalize_batched(d, &partials, &dw_unique, &dbias, 1, stream);
+}
+
+int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_unique, const int32_t* dgrad,
+                            void* const* packed, int32_t n, void* stream) {
+  if (!descs || !w_unique || !dgrad || !packed || n <= 0) return MC_EINVAL;
+  for (int base = 0; base < n; base += PK_MAX) {
+    PkTable t;
+    t.n = n - base < PK_MAX ? n - base : PK_MAX;
+    int blocks = 0;
+    for (int k = 0; k < t.n; ++k) {
+      ConvGeom g;
+      int rc = geom_for(&descs[base + k], g);
+      if (rc) return rc;
+      if (!w_unique[base + k] || !packed[base + k]) return MC_EINVAL;
+      PkJob& j = t.j[k];
+      j.K = g.K; j.Cout = g.Cout; j.CBin = g.CBin; j.CB0 = g.CB0; j.Cin0 = g.Cin0; j.Cin1 = g.Cin1; j.Cin = g.Cin; j.U = g.U;
+      j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = g.dtype == MC_BF16;
+      size_t total;
+      if (j.bf16) {
+        int chunks;
+        mc_bf16_bank_dims(g, j.dgrad, chunks, j.steps, j.ntiles);
+        total = (size_t)chunks * j.steps * j.ntiles * 64 * 8;
+      } else {
+        j.steps = 0; j.ntiles = 0;
+        total = (size_t)(j.dgrad ? g.CBout : g.CBin) * g.K * g.K * 8 * (j.dgrad ? g.CinP : g.CoutP);
+      }
+      j.total = (unsigned)total;
+      j.w = w_unique[base + k];
+      j.out = packed[base + k];
+      j.first_block = blocks;
+      int b = (int)((total + 256 * 8 - 1) / (256 * 8));
+      blocks += b < 1 ? 1 : b;
+    }
+    hipLaunchKernelGGL(k_pack_batched, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    MC_CHECK_LAUNCH();
+  }
   return MC_OK;
 }
 

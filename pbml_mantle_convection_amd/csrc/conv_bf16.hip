@@ -39,38 +39,9 @@ __host__ __device__ inline int pick_nt(int n_tiles) { return (n_tiles % 4 == 0) 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad, bf16_t* __restrict__ bank,
                             int chunks, int steps, int ntiles) {
-  const int K = g.K, KK = K * K;
   const size_t total = (size_t)chunks * steps * ntiles * 64 * 8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int e = (int)(i & 7);
-    int lane = (int)((i >> 3) & 63);
-    size_t r = i >> 9;
-    int nt = (int)(r % ntiles); r /= ntiles;
-    int s = (int)(r % steps);
-    int ck = (int)(r / steps);
-    int n = lane & 15, gq = lane >> 4;
-    int j = 4 * s + gq;
-    int tap = j / CHUNK_CB, cb = j % CHUNK_CB;
-    float v = 0.f;
-    if (tap < KK) {
-      int kin = ck * 16 + cb * 8 + e;     // padded input-channel index of this conv
-      int kout = nt * 16 + n;             // padded output-channel index of this conv
-      int co, cip;                        // forward (co, padded ci)
-      int ky = tap / K, kx = tap % K;
-      if (!dgrad) { co = kout; cip = kin; }
-      else { co = kin; cip = kout; ky = K - 1 - ky; kx = K - 1 - kx; }
-      int ob = cip / 8, oj = cip % 8;
-      bool ok = co < g.Cout && ob < g.CBin &&
-                (ob < g.CB0 ? (ob * 8 + oj < g.Cin0) : ((ob - g.CB0) * 8 + oj < g.Cin1));
-      if (ok) {
-        int ci = ob < g.CB0 ? ob * 8 + oj : g.Cin0 + (ob - g.CB0) * 8 + oj;
-        int u = co, kxs = kx;
-        if (co >= g.U) { u = co - g.U; kxs = K - 1 - kx; }
-        v = wu[(((size_t)u * g.Cin + ci) * K + ky) * K + kxs];
-      }
-    }
-    bank[i] = f2bf(v);
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    bank[i] = f2bf(pack_value_bf16(g, wu, i, dgrad, steps, ntiles));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,7 +528,7 @@ int mc_bf16_tile(const mc_conv_desc* d, int* th, int* tw) {
   return MC_OK;
 }
 
-static void bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles) {
+void mc_bf16_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles) {
   // forward conv: K over padded C_in, N over C_out; dgrad conv: K over C_out, N over padded C_in
   int cb_in = dgrad ? g.CBout : g.CBin;
   int c_out = dgrad ? g.CinP : g.Cout;
@@ -570,13 +541,13 @@ static void bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int
 
 size_t mc_bf16_bank_bytes(const ConvGeom& g, int dgrad) {
   int chunks, steps, ntiles;
-  bank_dims(g, dgrad, chunks, steps, ntiles);
+  mc_bf16_bank_dims(g, dgrad, chunks, steps, ntiles);
   return (size_t)chunks * steps * ntiles * 64 * 16;
 }
 
 int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hipStream_t s) {
   int chunks, steps, ntiles;
-  bank_dims(g, dgrad, chunks, steps, ntiles);
+  mc_bf16_bank_dims(g, dgrad, chunks, steps, ntiles);
   size_t total = (size_t)chunks * steps * ntiles * 64 * 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;

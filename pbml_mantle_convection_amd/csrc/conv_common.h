@@ -69,3 +69,54 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
 static __host__ __device__ inline int cin_padded_index(int ci, int Cin0, int CB0) {
   return ci < Cin0 ? ci : CB0 * 8 + (ci - Cin0);
 }
+
+// ------------------------------------------------------------------------------------------------
+// filter-bank element generators shared by the single-layer and the batched pack kernels.
+// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP.
+// ------------------------------------------------------------------------------------------------
+template <typename G>
+__device__ __forceinline__ float bank_source(const G& g, const float* __restrict__ wu, int co, int cip, int ky, int kx) {
+  // forward filter W_full[co][ci(cip)][ky][kx] read from the unique bank; cip = padded concat channel index
+  int ob = cip / 8, oj = cip % 8;
+  bool ok = co < g.Cout && ob < g.CBin && (ob < g.CB0 ? (ob * 8 + oj < g.Cin0) : ((ob - g.CB0) * 8 + oj < g.Cin1));
+  if (!ok) return 0.f;
+  int ci = ob < g.CB0 ? ob * 8 + oj : g.Cin0 + (ob - g.CB0) * 8 + oj;
+  int u = co, kxs = kx;
+  if (co >= g.U) { u = co - g.U; kxs = g.K - 1 - kx; }        // x-mirrored copy (symmetric_layers_torch.py:121-123)
+  return wu[(((size_t)u * g.Cin + ci) * g.K + ky) * g.K + kxs];
+}
+
+// f32 bank [cbin][tap][ci8][CoutP] (dgrad: [cb over C_out][tap][j][CinP], rotated taps)
+template <typename G>
+__device__ __forceinline__ float pack_value_f32(const G& g, const float* __restrict__ wu, size_t i, int dgrad) {
+  const int K = g.K, KK = K * K;
+  const int cop = dgrad ? g.CinP : g.CoutP;
+  int o = (int)(i % cop);
+  size_t r = i / cop;
+  int j = (int)(r % 8); r /= 8;
+  int tap = (int)(r % KK);
+  int cb = (int)(r / KK);
+  if (!dgrad) return bank_source(g, wu, o, cb * 8 + j, tap / K, tap % K);
+  return bank_source(g, wu, cb * 8 + j, o, K - 1 - tap / K, K - 1 - tap % K);
+}
+
+// bf16 bank [chunk][step][ntile][lane][8]; pair j = 4 step + (lane >> 4): tap = j / 2, cb = j % 2
+template <typename G>
+__device__ __forceinline__ float pack_value_bf16(const G& g, const float* __restrict__ wu, size_t i, int dgrad, int steps,
+                                                 int ntiles) {
+  const int K = g.K, KK = K * K;
+  int e = (int)(i & 7);
+  int lane = (int)((i >> 3) & 63);
+  size_t r = i >> 9;
+  int nt = (int)(r % ntiles); r /= ntiles;
+  int s = (int)(r % steps);
+  int ck = (int)(r / steps);
+  int n = lane & 15, gq = lane >> 4;
+  int j = 4 * s + gq;
+  int tap = j / 2, cb = j % 2;
+  if (tap >= KK) return 0.f;
+  int kin = ck * 16 + cb * 8 + e, kout = nt * 16 + n;
+  int ky = tap / K, kx = tap % K;
+  if (!dgrad) return bank_source(g, wu, kout, kin, ky, kx);
+  return bank_source(g, wu, kin, kout, K - 1 - ky, K - 1 - kx);
+}

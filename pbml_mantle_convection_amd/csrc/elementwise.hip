@@ -295,12 +295,44 @@ __global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blo
 }
 
 // phase 3: dy = rstd (dz gamma - m1 - yhat m2)   (GN)   |   dy = da act'(y)   (act only)
-template <typename T>
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restrict__ y, const float* __restrict__ m12,
-                                                      mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy) {
+                                                      mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy,
+                                                      const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta) {
   const int n = blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8], mean[8], rstd[8], ga[8], m1[8], m2[8];
   gn_coef(a, n, cb, sc, sh);
+  __shared__ float fsum[4][16];
+  if (FUSED) {
+    // phase 2 inside phase 3: sum the phase-1 partials of this channel block (nblk x 8 channels x 2)
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int CP = a.C8 * 8;
+    for (int t = threadIdx.x; t < nblk; t += blockDim.x) {
+      const float4* p = reinterpret_cast<const float4*>(part + (((size_t)n * nblk + t) * CP + cb * 8) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = p[q];
+        acc[q * 4 + 0] += v.x; acc[q * 4 + 1] += v.y; acc[q * 4 + 2] += v.z; acc[q * 4 + 3] += v.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float r = wave_sum(acc[j]);
+      if ((threadIdx.x & 63) == 0) fsum[threadIdx.x >> 6][j] = r;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+      int c = cb * 8 + (threadIdx.x >> 1);
+      if (c < a.C) {
+        float r = (fsum[0][threadIdx.x] + fsum[1][threadIdx.x]) + (fsum[2][threadIdx.x] + fsum[3][threadIdx.x]);
+        if (threadIdx.x & 1) { if (dgamma) atomicAdd(dgamma + c, r); }      // sum dz * yhat
+        else if (dbeta) atomicAdd(dbeta + c, r);                             // sum dz
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int c = cb * 8 + j;
@@ -311,8 +343,22 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
         mean[j] = a.stats[((size_t)n * a.groups + g) * 2];
         rstd[j] = a.stats[((size_t)n * a.groups + g) * 2 + 1];
         ga[j] = a.gamma[c];
-        m1[j] = m12[((size_t)n * a.groups + g) * 2];
-        m2[j] = m12[((size_t)n * a.groups + g) * 2 + 1];
+        if (FUSED) {
+          // group sums over the cpg channels of this group (all inside this channel block: cpg divides 8)
+          const float M = (float)a.cpg * (float)(a.H * a.W);
+          float t1 = 0.f, t2 = 0.f;
+          for (int cc = g * a.cpg; cc < (g + 1) * a.cpg; ++cc) {
+            int jj = cc - cb * 8;
+            float gg = a.gamma[cc];
+            t1 += gg * ((fsum[0][jj * 2] + fsum[1][jj * 2]) + (fsum[2][jj * 2] + fsum[3][jj * 2]));
+            t2 += gg * ((fsum[0][jj * 2 + 1] + fsum[1][jj * 2 + 1]) + (fsum[2][jj * 2 + 1] + fsum[3][jj * 2 + 1]));
+          }
+          m1[j] = t1 / M;
+          m2[j] = t2 / M;
+        } else {
+          m1[j] = m12[((size_t)n * a.groups + g) * 2];
+          m2[j] = m12[((size_t)n * a.groups + g) * 2 + 1];
+        }
       } else { ga[j] = 1.f; rstd[j] = 1.f; }
     }
   }
@@ -775,8 +821,8 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   if (post == MC_POST_NONE) a.act = MC_ACT_NONE;
   dim3 g(cdiv(h, GN_ROWS), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_bwd_apply<float>, g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_bwd_apply<bf16_t>, g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy);
+  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, false>), g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, nullptr, 0, nullptr, nullptr);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, false>), g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, nullptr, 0, nullptr, nullptr);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -793,6 +839,25 @@ int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int3
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded<float>, g, dim3(256), 0, s, (float*)buf, C8, hs, ws, pad, pad_mode, all);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_fold_padded<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
+                              const float* partials, int32_t blocks, const float* gamma, const float* beta, int32_t act,
+                              int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, float* dgamma, float* dbeta,
+                              void* dy, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, MC_POST_GN_ACT, act);
+  if (rc) return rc;
+  if (!y || !dy || !g0 || !partials || blocks <= 0) return MC_EINVAL;
+  if (a.cpg > 8 || (8 % a.cpg) != 0) return MC_EUNSUPPORTED;   // a group must not straddle 8-channel blocks
+  if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
+  dim3 g(cdiv(h, GN_ROWS), a.C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, true>), g, dim3(256), 0, s, a, (const float*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, partials, blocks, dgamma, dbeta);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, true>), g, dim3(256), 0, s, a, (const bf16_t*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, partials, blocks, dgamma, dbeta);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;

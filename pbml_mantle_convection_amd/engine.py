@@ -349,14 +349,15 @@ class Engine:
                 hp, wp = h + 2 * node.pad, w + 2 * node.pad
                 e["dxp"] = [cb8(s.C, hp, wp) for s in srcs]
             max_dy = max(max_dy, N * coutp * ho * wo)
-            max_wg = max(max_wg, L.call("mc_wgrad_partial_bytes", C.byref(d)))
+            # per-layer filter-gradient partial slabs: all layers are combined by ONE batched launch at the end of backward
+            e["wpart"] = torch.empty(L.call("mc_wgrad_partial_bytes", C.byref(d)), dtype=torch.uint8, device=device)
             self.plan.append(e)
         self.T = T
         # two dY buffers: the filter gradient of layer L runs on a side stream while the main stream already
         # prepares dY of layer L-1 (see backward)
         self.dYs = [torch.empty(max_dy, dtype=self.t_dtype, device=device) for _ in range(2)]
         self.dY = self.dYs[0]
-        self.wg_part = torch.empty(max_wg, dtype=torch.uint8, device=device)
+        self.convs = [e for e in self.plan if e["node"].kind == "conv"]
         self.side = torch.cuda.Stream(device=device)
         last = self.plan[-1]
         assert last["node"].kind == "conv", "graph must end in a conv node"
@@ -392,6 +393,7 @@ class Engine:
         act = L.ACTS[g.act]
         L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
                L.ptr(T[0].buf), st)
+        self._pack_all_banks(params, st)
         for e in self.plan:
             node = e["node"]
             if node.kind == "up":
@@ -403,7 +405,6 @@ class Engine:
             d = e["desc"]
             w = self._param(params, node.name + "weight")
             b = self._param(params, node.name + "bias")
-            L.call("mc_pack_weights", C.byref(d), L.ptr(w), 0, L.ptr(e["bank"]), st)
             srcs = [T[i] for i in node.srcs]
             o = T[node.out]
             final = node.post == L.POST_NONE
@@ -496,16 +497,25 @@ class Engine:
                 g1 = C.byref(gs[1]) if len(gs) > 1 else None
                 gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
                 beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
+                cpg = node.c_out // max(node.groups, 1)
                 if node.post == L.POST_GN_ACT:
                     L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
                            L.ptr(e["gpart"]), st)
-                    L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
-                           o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
-                           L.ptr(grads[node.gn_name + "bias"]), st)
-                L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
-                       L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
-                       self.mc_dtype, g0, g1, L.ptr(dY), st)
+                if node.post == L.POST_GN_ACT and cpg <= 8 and 8 % cpg == 0:
+                    # phases 2 + 3 in one launch (the per-(n, group) means are re-derived per workgroup)
+                    L.call("mc_gn_act_bwd_apply_fused", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                           L.ptr(e["stats"]), L.ptr(e["gpart"]), e["gblocks"], L.ptr(gamma), L.ptr(beta), act,
+                           self.mc_dtype, g0, g1, L.ptr(grads[node.gn_name + "weight"]),
+                           L.ptr(grads[node.gn_name + "bias"]), L.ptr(dY), st)
+                else:
+                    if node.post == L.POST_GN_ACT:
+                        L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
+                               o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
+                               L.ptr(grads[node.gn_name + "bias"]), st)
+                    L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                           L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
+                           self.mc_dtype, g0, g1, L.ptr(dY), st)
             x0 = L.ptr(srcs[0].buf)
             x1 = L.ptr(srcs[1].buf) if len(srcs) > 1 else None
             if side is not main:
@@ -514,16 +524,12 @@ class Engine:
                 side.wait_event(ev)
             with torch.cuda.stream(side):
                 ss = L.stream()
-                L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(self.wg_part), ss)
-                L.call("mc_conv2d_wgrad_finalize", C.byref(d), L.ptr(self.wg_part), L.ptr(grads[node.name + "weight"]),
-                       L.ptr(grads[node.name + "bias"]), ss)
+                L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(e["wpart"]), ss)
                 if side is not main:
                     wg_done[k & 1] = torch.cuda.Event()
                     wg_done[k & 1].record(side)
             k += 1
             if e["need_dgrad"]:
-                w = self._param(params, node.name + "weight")
-                L.call("mc_pack_weights", C.byref(d), L.ptr(w), 1, L.ptr(e["dbank"]), st)
                 dxp = e["dxp"]
                 self._probe_begin()
                 L.call("mc_conv2d", C.byref(e["ddesc"]), L.ptr(dY), None, L.ptr(e["dbank"]), None, L.ptr(dxp[0]),
@@ -535,6 +541,29 @@ class Engine:
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(side)
+        # one launch combines every layer's partial slabs, folds mirrored filters and accumulates into the gradients
+        n = len(self.convs)
+        descs = (L.ConvDesc * n)(*[e["desc"] for e in self.convs])
+        parts = (C.c_void_p * n)(*[L.ptr(e["wpart"]) for e in self.convs])
+        dws = (C.c_void_p * n)(*[L.ptr(grads[e["node"].name + "weight"]) for e in self.convs])
+        dbs = (C.c_void_p * n)(*[L.ptr(grads[e["node"].name + "bias"]) for e in self.convs])
+        L.call("mc_conv2d_wgrad_finalize_batched", descs, parts, dws, dbs, n, st)
+
+    def _pack_all_banks(self, params, st):
+        """Forward and input-gradient banks of every layer in one batched launch per 24 jobs (weights are fixed
+        within a step)."""
+        jobs = []
+        for e in self.convs:
+            w = self._param(params, e["node"].name + "weight")
+            jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))
+            if e["need_dgrad"]:
+                jobs.append((e["desc"], L.ptr(w), 1, L.ptr(e["dbank"])))
+        n = len(jobs)
+        descs = (L.ConvDesc * n)(*[j[0] for j in jobs])
+        ws = (C.c_void_p * n)(*[j[1] for j in jobs])
+        dg = (C.c_int32 * n)(*[j[2] for j in jobs])
+        outs = (C.c_void_p * n)(*[j[3] for j in jobs])
+        L.call("mc_pack_weights_batched", descs, ws, dg, outs, n, st)
 
     # -------------------------------------------------------------- measurement hooks (bench.py)
     _probe = None
