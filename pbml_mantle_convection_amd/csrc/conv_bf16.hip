@@ -71,12 +71,16 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   constexpr int MTILES_X = TW / 16;
   static_assert(TH * MTILES_X == 4 * MT, "tile / wave decomposition mismatch");
   constexpr int IN_SLOTS = CHUNK_CB * PLANE;
-  constexpr int W_SLOTS = STEPS * NT * 64;
+  // NT == 1: the bank slice (13 KiB) is staged in LDS once per chunk.  NT > 1 (deep, channel-heavy layers): the slice
+  // would be 27-53 KiB per chunk and re-staging it dominated the per-workgroup critical path, so B fragments are read
+  // straight from the L2-resident bank (each lane's fragment is one contiguous 16-byte load) a K-step ahead.
+  constexpr bool WGLOBAL = NT > 1;
+  constexpr int W_SLOTS = WGLOBAL ? 0 : STEPS * NT * 64;
   static_assert(!OUT_F32 || NT == 1, "f32 output is for the single-N-tile configuration");
   constexpr int IN_ELEMS = CHUNK_CB * TIH * TIW;
   constexpr int IN_ITERS = (IN_ELEMS + 255) / 256;
-  constexpr int W_ITERS = (W_SLOTS + 255) / 256;
-  __shared__ uint4 lds[IN_SLOTS + W_SLOTS];
+  constexpr int W_ITERS = WGLOBAL ? 1 : (W_SLOTS + 255) / 256;
+  __shared__ uint4 lds[IN_SLOTS + (WGLOBAL ? 1 : W_SLOTS)];
   __shared__ float red[4][NT * 16 * 2];
   uint4* in_s = lds;
   uint4* w_s = lds + IN_SLOTS;
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     if (!PREFETCH) prefetch(t);
     __syncthreads();                                            // LDS free: previous MFMA loop done
     commit();
-    if (chunks > 1 || t == 0) stage_weights(ck);
+    if (!WGLOBAL && (chunks > 1 || t == 0)) stage_weights(ck);
+    const uint4* wglob = reinterpret_cast<const uint4*>(bank) + ((size_t)ck * STEPS * ntiles_total + ntile0) * 64 + lane;
     __syncthreads();
     if (PREFETCH && t + 1 < total_stages) prefetch(t + 1);      // in flight during the MFMA loop
     // ---- MFMA loop (rolled over the K-steps: the per-lane operand offset is recomputed per step)
@@ -211,7 +216,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
       kx += 2;
       if (kx >= K) { kx -= K; ky += 1; }
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(sidx * NT + tt) * 64 + lane]);
+      for (int tt = 0; tt < NT; ++tt) {
+        if (WGLOBAL) {
+          uint4 wv = wglob[((size_t)sidx * ntiles_total + tt) * 64];
+          wf[tt] = __builtin_bit_cast(bf16x8, wv);
+        } else {
+          wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(sidx * NT + tt) * 64 + lane]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
         xf[i] = *reinterpret_cast<const bf16x8*>(ap + (i / MTILES_X) * TIW + (i % MTILES_X) * 16);
@@ -226,6 +238,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
 #define MC_KPIPE 0   /* A/B on MI355X: ping-pong fragment registers gave no gain (the level-0 layers sit at ~2.5 TB/s algorithmic) */
 #endif
 #if MC_KPIPE
+#error "MC_KPIPE is selected per configuration below"
+#endif
+    if constexpr (WGLOBAL) {
     bf16x8 xa[MT], xb[MT], wa[NT], wb[NT];
     load_frags(0, xa, wa);
 #pragma unroll 1
@@ -235,14 +250,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
       if (s + 2 < STEPS) load_frags(s + 2, xa, wa);
       if (s + 1 < STEPS) do_mfma(xb, wb);
     }
-#else
+    } else {
     bf16x8 xa[MT], wa[NT];
 #pragma unroll 1
     for (int s = 0; s < STEPS; ++s) {
       load_frags(s, xa, wa);
       do_mfma(xa, wa);
     }
-#endif
+    }
     if (ck != chunks - 1) continue;
 
     // ---- epilogue of this work item, straight from the accumulators
