@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   // NT == 1: the bank slice (13 KiB) is staged in LDS once per chunk.  NT > 1 (deep, channel-heavy layers): the slice
   // would be 27-53 KiB per chunk and re-staging it dominated the per-workgroup critical path, so B fragments are read
   // straight from the L2-resident bank (each lane's fragment is one contiguous 16-byte load) a K-step ahead.
-  constexpr bool WGLOBAL = NT > 1;
+#ifndef MC_WGLOBAL_ALL
+#define MC_WGLOBAL_ALL 0
+#endif
+  constexpr bool WGLOBAL = NT > 1 || MC_WGLOBAL_ALL;
   constexpr int W_SLOTS = WGLOBAL ? 0 : STEPS * NT * 64;
   static_assert(!OUT_F32 || NT == 1, "f32 output is for the single-N-tile configuration");
   constexpr int IN_ELEMS = CHUNK_CB * TIH * TIW;

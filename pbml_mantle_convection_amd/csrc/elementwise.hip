@@ -236,33 +236,18 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __rest
     } else { mean[j] = 0.f; rstd[j] = 0.f; }
   }
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // four independent (row, column) vectors per iteration: their loads are issued before any arithmetic so that
-  // several 16-byte requests per lane are in flight (one at a time left these kernels latency-bound at small sizes)
-  for (int y0 = blk; y0 < a.H; y0 += 2 * nblk)
-    for (int x0 = threadIdx.x; x0 < a.W; x0 += 2 * blockDim.x) {
-      float v[4][8], da[4][8];
-      bool ok[4];
+  for (int yy = blk; yy < a.H; yy += nblk)
+    for (int xx = threadIdx.x; xx < a.W; xx += blockDim.x) {
+      float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
+      grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
+      grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int yy = y0 + (u >> 1) * nblk, xx = x0 + (u & 1) * blockDim.x;
-        ok[u] = yy < a.H && xx < a.W;
-        yy = min(yy, a.H - 1); xx = min(xx, a.W - 1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) da[u][j] = 0.f;
-        V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v[u]);
-        grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da[u]);
-        grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da[u]);
+      for (int j = 0; j < 8; ++j) {
+        float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
+        s1[j] += dz;
+        s2[j] += dz * (v[j] - mean[j]) * rstd[j];
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u]) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float dz = da[u][j] * act_bwd_t<FastMath<T>::value>(v[u][j] * sc[j] + sh[j], a.act);
-            s1[j] += dz;
-            s2[j] += dz * (v[u][j] - mean[j]) * rstd[j];
-          }
-        }
     }
   __shared__ float red[4][16];
 #pragma unroll
@@ -379,41 +364,28 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
   }
   // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over
   // >= 8 vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s)
-  const int yend = min((int)(blockIdx.x + 1) * GN_ROWS, a.H);
-  for (int y0 = blockIdx.x * GN_ROWS; y0 < yend; y0 += 2)
-    for (int x0 = threadIdx.x; x0 < a.W; x0 += 2 * blockDim.x) {
-      float v[4][8], da[4][8];
-      bool ok[4];
-      size_t idx[4];
+  // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over several
+  // vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s).  (A 4-way manual batching
+  // of the loads was tried and was SLOWER: 131 VGPRs cut the occupancy of this streaming kernel.)
+  for (int yy = blockIdx.x * GN_ROWS; yy < min((int)(blockIdx.x + 1) * GN_ROWS, a.H); ++yy)
+  for (int xx = threadIdx.x; xx < a.W; xx += blockDim.x) {
+    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+    size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
+    V8<T>::ld(y + idx, v);
+    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int yy = y0 + (u >> 1), xx = x0 + (u & 1) * blockDim.x;
-        ok[u] = yy < yend && xx < a.W;
-        yy = min(yy, a.H - 1); xx = min(xx, a.W - 1);
-        idx[u] = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) da[u][j] = 0.f;
-        V8<T>::ld(y + idx[u], v[u]);
-        grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da[u]);
-        grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da[u]);
+    for (int j = 0; j < 8; ++j) {
+      float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
+      if (a.post == MC_POST_GN_ACT) {
+        float yh = (v[j] - mean[j]) * rstd[j];
+        o[j] = rstd[j] * (dz * ga[j] - m1[j] - yh * m2[j]);
+      } else {
+        o[j] = dz * ga[j];
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u]) {
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float dz = da[u][j] * act_bwd_t<FastMath<T>::value>(v[u][j] * sc[j] + sh[j], a.act);
-            if (a.post == MC_POST_GN_ACT) {
-              float yh = (v[u][j] - mean[j]) * rstd[j];
-              o[j] = rstd[j] * (dz * ga[j] - m1[j] - yh * m2[j]);
-            } else {
-              o[j] = dz * ga[j];
-            }
-          }
-          V8<T>::st(dy + idx[u], o);
-        }
     }
+    V8<T>::st(dy + idx, o);
+  }
 }
 
 // in-place adjoint of F.pad on a padded-domain gradient: one thread per border TARGET pixel (a pixel of the

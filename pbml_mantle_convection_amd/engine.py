@@ -265,6 +265,7 @@ class Engine:
         self.mc_dtype, self.t_dtype = DTYPES[precision]
         self.shape = None
         self._tables = {}
+        self.fused_gn_bwd = os.environ.get("MANTLE_FUSED_GN_BWD", "0") != "0"   # A/B on MI355X: the fused form is 0.45 ms/step slower (131 VGPRs)
         self.overlap_wgrad = os.environ.get("MANTLE_OVERLAP_WGRAD", "0") != "0"   # A/B on MI355X: no gain, every kernel already fills the chip
 
     # -------------------------------------------------------------- planning
@@ -502,7 +503,7 @@ class Engine:
                     L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
                            L.ptr(e["gpart"]), st)
-                if node.post == L.POST_GN_ACT and cpg <= 8 and 8 % cpg == 0:
+                if self.fused_gn_bwd and node.post == L.POST_GN_ACT and cpg <= 8 and 8 % cpg == 0:
                     # phases 2 + 3 in one launch (the per-(n, group) means are re-derived per workgroup)
                     L.call("mc_gn_act_bwd_apply_fused", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e["stats"]), L.ptr(e["gpart"]), e["gblocks"], L.ptr(gamma), L.ptr(beta), act,
