@@ -23,6 +23,14 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// XCD-aware work-group id: hardware deals consecutive blockIdx round-robin over the 8 XCDs (each with a private L2);
+// remap so that every XCD owns a CONTIGUOUS range of ids -> spatially adjacent tiles (which share their input halo)
+// run on the same XCD and the halo re-reads hit that XCD's L2.  Bijective for any grid size (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 constexpr int CHUNK_CB = 2;     // 8-channel blocks per K-chunk (16 input channels)
 
 template <int K> struct KSteps { static constexpr int pairs = K * K * CHUNK_CB; static constexpr int steps = (pairs + 3) / 4; };
@@ -89,13 +97,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   uint4* w_s = lds + IN_SLOTS;
 
   const int grp = blockIdx.y;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, gq = lane >> 4;
   const int ntile0 = grp * NT;                                  // first global N-tile of this block
   const int ntiles_total = gridDim.y * NT;
   const int chunks = (g.CBin + CHUNK_CB - 1) / CHUNK_CB;
   const int items = g.N * g.tiles;
-  const int my_items = (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int my_items = (items - bid + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total_stages = my_items * chunks;
 
   // Staging loads are raw buffer loads: one descriptor per (image, source tensor); an out-of-range offset
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   }
   auto prefetch = [&](int t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
-    const int wi = blockIdx.x + jitem * gridDim.x;
+    const int wi = bid + jitem * gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     if (ck != chunks - 1) continue;
 
     // ---- epilogue of this work item, straight from the accumulators
-    const int wi = blockIdx.x + jitem * gridDim.x;
+    const int wi = bid + jitem * gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     float s1[NT][4], s2[NT][4];
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   __shared__ uint4 xs[2 * XPS];
   __shared__ uint4 ds[NTW * 2 * DPS];
   const int chunk = blockIdx.y, cog = blockIdx.z;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
   // per-lane short offsets (2-byte units) inside a plane pair for pixel 8g + q of a row start
@@ -481,8 +491,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     for (int t = 0; t < NTW; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int work = g.N * tiles;
-  if ((int)blockIdx.x < work) prefetch(blockIdx.x);
-  for (int wi = blockIdx.x; wi < work; wi += gridDim.x) {
+  if (bid < work) prefetch(bid);
+  for (int wi = bid; wi < work; wi += gridDim.x) {
     __syncthreads();
     commit();
     __syncthreads();
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   }
   // ---- write this block's partial slab
   const int cols = g.CinP * KK + 1;
-  float* pb = part + (size_t)blockIdx.x * g.CoutP * cols;
+  float* pb = part + (size_t)bid * g.CoutP * cols;
   const int cip = chunk * 16 + (lane & 15);
 #pragma unroll
   for (int ti = 0; ti < NTAP; ++ti) {
