@@ -222,11 +222,12 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
                     int64_t pred_batch_stride, int64_t p_batch_stride, const float* uvp, const float* mm,
                     double* sums, float* gu, float* gv, float* gp, float* gT, void* stream);
 /* Stokes momentum residual (build-defined).  yc [h][w], paras [n][3] =
- * (RaQ, FKT, FKP), scaler [n].  sx, sy: workspaces [n][h][w] f32. */
+ * (RaQ, FKT, FKP), scaler [n].  sx, sy, eta_ws: workspaces [n][h][w] f32 (eta_ws receives the viscosity
+ * field computed by mc_momentum_residual and is read again by mc_momentum_adjoint). */
 int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, const float* p,
                          const float* T, int64_t pred_batch_stride, int64_t p_batch_stride, const float* yc, const float* paras,
-                         const float* scaler, double* sums, float* sx, float* sy, void* stream);
-int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pred_batch_stride, int64_t p_batch_stride, const float* yc,
+                         const float* scaler, double* sums, float* sx, float* sy, float* eta_ws, void* stream);
+int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pred_batch_stride, int64_t p_batch_stride, const float* eta_ws,
                         const float* paras, const float* scaler, const float* sx, const float* sy,
                         float* gu, float* gv, float* gp, float* gT, void* stream);
 /* loss6 (+momentum) from the sums, exactly as get_loss combines them: out[8] f32 =

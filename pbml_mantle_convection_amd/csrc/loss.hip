@@ -178,11 +178,8 @@ struct MomGeom {
 };
 
 struct MomField {
-  const float* T; const float* yc; float lnfkt, lnfkp; int H, W;
-  __device__ __forceinline__ float eta(int i, int j) const {
-    float e = expf(-lnfkt * T[(size_t)i * W + j] + lnfkp * (1.0f - yc[(size_t)i * W + j]));
-    return fminf(fmaxf(e, 1e-8f), 1.0f);
-  }
+  const float* etab; int H, W;     // viscosity field of this sample, precomputed once by k_mom_eta
+  __device__ __forceinline__ float eta(int i, int j) const { return etab[(size_t)i * W + j]; }
   __device__ __forceinline__ float exf(int i, int j) const {  // x-face (i, j+1/2)
     if (i < 0 || i >= H || j < 0 || j > W - 2) return 0.f;
     return 0.5f * (eta(i, j) + eta(i, j + 1));
@@ -193,9 +190,21 @@ struct MomField {
   }
 };
 
+// eta = clip(exp(-ln(FKT) T + ln(FKP) (1 - y)), 1e-8, 1): one exp per pixel instead of ~20 per residual evaluation
+__global__ void k_mom_eta(int HW, int64_t pbs, const float* __restrict__ T_, const float* __restrict__ yc,
+                          const float* __restrict__ paras, float* __restrict__ eta) {
+  const int n = blockIdx.y;
+  const float lnfkt = logf(paras[n * 3 + 1]), lnfkp = logf(paras[n * 3 + 2]);
+  const float* T = T_ + (size_t)n * pbs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    float e = expf(-lnfkt * T[i] + lnfkp * (1.0f - yc[i]));
+    eta[(size_t)n * HW + i] = fminf(fmaxf(e, 1e-8f), 1.0f);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
                                                       const float* __restrict__ p_, const float* __restrict__ T_,
-                                                      const float* __restrict__ yc, const float* __restrict__ paras,
+                                                      const float* __restrict__ eta_, const float* __restrict__ paras,
                                                       const float* __restrict__ scaler, double* __restrict__ sums,
                                                       float* __restrict__ sx_, float* __restrict__ sy_) {
   const int H = g.H, W = g.W, HW = H * W, n = blockIdx.y;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
   const float* v = v_ + (size_t)n * g.pbs;
   const float* p = p_ ? p_ + (size_t)n * g.ppbs : nullptr;
   const float* T = T_ + (size_t)n * g.pbs;
-  MomField f{T, yc, logf(paras[n * 3 + 1]), logf(paras[n * 3 + 2]), H, W};
+  MomField f{eta_ + (size_t)n * HW, H, W};
   const float s = scaler[n], ih = g.ih;
   const float c = g.lam / ((float)g.N * (float)(H - 2) * (float)(W - 2));
   double ax = 0, ay = 0;
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
   bs.flush<2>(sums, slots);
 }
 
-__global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ T_, const float* __restrict__ yc,
+__global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ T_, const float* __restrict__ eta_,
                                                      const float* __restrict__ paras, const float* __restrict__ scaler,
                                                      const float* __restrict__ sx_, const float* __restrict__ sy_,
                                                      float* __restrict__ gu_, float* __restrict__ gv_,
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
   const float* T = T_ + (size_t)n * g.pbs;
   const float* sx = sx_ + (size_t)n * HW;
   const float* sy = sy_ + (size_t)n * HW;
-  MomField f{T, yc, logf(paras[n * 3 + 1]), logf(paras[n * 3 + 2]), H, W};
+  MomField f{eta_ + (size_t)n * HW, H, W};
   const float s = scaler[n], ih = g.ih;
   auto SX = [&](int i, int j) { return (i < 0 || i >= H || j < 0 || j >= W) ? 0.f : sx[(size_t)i * W + j]; };
   auto SY = [&](int i, int j) { return (i < 0 || i >= H || j < 0 || j >= W) ? 0.f : sy[(size_t)i * W + j]; };
@@ -333,26 +342,27 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
 
 int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
                          int64_t pbs, int64_t ppbs, const float* yc, const float* paras, const float* scaler,
-                         double* sums, float* sx, float* sy, void* stream) {
+                         double* sums, float* sx, float* sy, float* eta_ws, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
-  if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy) return MC_EINVAL;
+  if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy || !eta_ws) return MC_EINVAL;
   MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
   dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
-  hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, yc, paras, scaler, sums, sx, sy);
+  hipLaunchKernelGGL(k_mom_eta, grid, dim3(256), 0, (hipStream_t)stream, d->h * d->w, pbs, T, yc, paras, eta_ws);
+  hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, eta_ws, paras, scaler, sums, sx, sy);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
 
-int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, int64_t ppbs, const float* yc, const float* paras,
+int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, int64_t ppbs, const float* eta_ws, const float* paras,
                         const float* scaler, const float* sx, const float* sy, float* gu, float* gv, float* gp,
                         float* gT, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
-  if (!T || !yc || !paras || !scaler || !sx || !sy || !gu || !gv) return MC_EINVAL;
+  if (!T || !eta_ws || !paras || !scaler || !sx || !sy || !gu || !gv) return MC_EINVAL;
   MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
   dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
-  hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, T, yc, paras, scaler, sx, sy, gu, gv, gp, gT,
+  hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, T, eta_ws, paras, scaler, sx, sy, gu, gv, gp, gT,
                      d->t_grad);
   MC_CHECK_LAUNCH();
   return MC_OK;

@@ -47,6 +47,7 @@ class StokesLoss:
         if self.lambda_mom != 0.0:
             self.sx = torch.empty((N, H, W), **f32)
             self.sy = torch.empty((N, H, W), **f32)
+            self.eta = torch.empty((N, H, W), **f32)
         self._shape = (N, Cc, H, W, str(dev))
 
     def channels_needed(self):
@@ -108,8 +109,8 @@ class StokesLoss:
             paras = paras.reshape(N, 3).float().contiguous()
             scaler = scaler.reshape(N).float().contiguous()
             L.call("mc_momentum_residual", C.byref(d), u, v, p, T, pbs, ppbs, L.ptr(yc), L.ptr(paras), L.ptr(scaler),
-                   L.ptr(self.sums), L.ptr(self.sx), L.ptr(self.sy), st)
-            L.call("mc_momentum_adjoint", C.byref(d), T, pbs, ppbs, L.ptr(yc), L.ptr(paras), L.ptr(scaler),
+                   L.ptr(self.sums), L.ptr(self.sx), L.ptr(self.sy), L.ptr(self.eta), st)
+            L.call("mc_momentum_adjoint", C.byref(d), T, pbs, ppbs, L.ptr(self.eta), L.ptr(paras), L.ptr(scaler),
                    L.ptr(self.sx), L.ptr(self.sy), gu, gv, gp, gT, st)
         if self.loss_type == "curl":
             L.call("mc_curl_head_bwd", gu, gv, gT, yb + 4 * HW, N, H, W, self.a_bound, 0.0, 1.5, gb, gb + 4 * HW,
