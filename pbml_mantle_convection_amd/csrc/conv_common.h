@@ -53,7 +53,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
     int ntw = (ntiles % 2 == 0) ? 2 : 1;
     long other = (long)((g.CBin + 1) / 2) * ((ntiles + ntw - 1) / ntw);
     G = (768 + other - 1) / other;
-    if (G < 32) G = 32;
+    if (G < 16) G = 16;
     work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
   } else {
     G = 1024;

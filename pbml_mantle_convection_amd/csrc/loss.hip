@@ -306,6 +306,15 @@ __global__ void k_loss_finalize(mc_loss_desc d, const double* __restrict__ s, fl
   out[5] = (float)mass; out[6] = (float)mom; out[7] = 0.f;
 }
 
+// workgroups per sample for the reducing loss kernels: every block ends in one f64 atomic per slot on a handful of
+// addresses (serialised at ~10 ns each), so keep the total near 2-4 blocks per CU and grid-stride the pixels
+int loss_blocks(int hw, int n) {
+  int b = cdiv(1024, n);
+  int most = cdiv(hw, 256);
+  if (b > most) b = most;
+  return b < 1 ? 1 : b;
+}
+
 int check_loss_desc(const mc_loss_desc* d) {
   if (!d || d->n <= 0 || d->h < 5 || d->w < 5) return MC_EINVAL;
   if (d->loss_type < 0 || d->loss_type > 2) return MC_EINVAL;
@@ -333,7 +342,7 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
   if (d->loss_scale && !mm) return MC_EINVAL;
   LossGeom g;
   g.d = *d; g.ct = d->p_pred ? 4 : 3; g.pbs = pbs; g.ppbs = ppbs;
-  dim3 grid(min(cdiv(d->h * d->w, 256 * 4), 256), d->n);
+  dim3 grid(loss_blocks(d->h * d->w, d->n), d->n);
   hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
                      gu, gv, d->p_pred ? gp : nullptr, gT);
   MC_CHECK_LAUNCH();
@@ -347,7 +356,7 @@ int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, 
   if (rc) return rc;
   if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy || !eta_ws) return MC_EINVAL;
   MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
-  dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
+  dim3 grid(loss_blocks(d->h * d->w, d->n), d->n);
   hipLaunchKernelGGL(k_mom_eta, grid, dim3(256), 0, (hipStream_t)stream, d->h * d->w, pbs, T, yc, paras, eta_ws);
   hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, eta_ws, paras, scaler, sums, sx, sy);
   MC_CHECK_LAUNCH();
