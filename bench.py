@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
+    p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     return p.parse_args()
 
 
@@ -110,11 +111,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev)              # (rehearsals may oversubscribe one GPU with gloo)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from pbml_mantle_convection_amd import _lib as L
     from pbml_mantle_convection_amd.datasetio import synthetic_batch
@@ -131,7 +136,7 @@ def main():
                  use_symm=CFG["use_symm"], repeats=CFG["repeats"], f=CFG["f"], p_pred=CFG["p_pred"])
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10 ** 9], gamma=0.5)
-    tr = Trainer(model, None, None, None, None, None, opt, sch, local_rank, 1, "/tmp/", p_pred=True, network="unet",
+    tr = Trainer(model, None, None, None, None, None, opt, sch, local_rank % ndev, 1, "/tmp/", p_pred=True, network="unet",
                  loss_scale=False, loss_derivative=False, loss_type=CFG["loss_type"], lambda_mom=args.lambda_mom,
                  precision=args.precision, use_graph=not args.no_graph)
     # synthetic fields, resident in HBM before the timed region (seed differs per rank: independent shards)
