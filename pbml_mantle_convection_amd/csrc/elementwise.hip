@@ -236,19 +236,22 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __rest
     } else { mean[j] = 0.f; rstd[j] = 0.f; }
   }
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int yy = blk; yy < a.H; yy += nblk)
-    for (int xx = threadIdx.x; xx < a.W; xx += blockDim.x) {
-      float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
-      grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
-      grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+  // rows blk, blk + nblk, ... of this block, flattened with the columns so that narrow images (W < 256) still use every
+  // thread (a per-row loop left 7/8 of the threads idle at the deep levels: ~25 us floor per launch)
+  const int nrows = (a.H - blk + nblk - 1) / nblk;
+  for (int i = threadIdx.x; i < nrows * a.W; i += blockDim.x) {
+    const int ry = i / a.W, xx = i - ry * a.W, yy = blk + ry * nblk;
+    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
+    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
-        s1[j] += dz;
-        s2[j] += dz * (v[j] - mean[j]) * rstd[j];
-      }
+    for (int j = 0; j < 8; ++j) {
+      float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
+      s1[j] += dz;
+      s2[j] += dz * (v[j] - mean[j]) * rstd[j];
     }
+  }
   __shared__ float red[4][16];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -367,8 +370,9 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
   // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over several
   // vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s).  (A 4-way manual batching
   // of the loads was tried and was SLOWER: 131 VGPRs cut the occupancy of this streaming kernel.)
-  for (int yy = blockIdx.x * GN_ROWS; yy < min((int)(blockIdx.x + 1) * GN_ROWS, a.H); ++yy)
-  for (int xx = threadIdx.x; xx < a.W; xx += blockDim.x) {
+  const int y0 = blockIdx.x * GN_ROWS, nrows = min(GN_ROWS, a.H - y0);
+  for (int i = threadIdx.x; i < nrows * a.W; i += blockDim.x) {      // rows x columns flattened (narrow images)
+    const int ry = i / a.W, xx = i - ry * a.W, yy = y0 + ry;
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
     size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
     V8<T>::ld(y + idx, v);
