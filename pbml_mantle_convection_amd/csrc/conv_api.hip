@@ -57,7 +57,7 @@ __global__ void k_pack_batched(PkTable t) {
   }
 }
 
-// dW_unique[u][ci][ky][kx] += sum_G part[G][u][...] + (u < h/2) sum_G part[G][U+u][..][ky][K-1-kx]
+// dW_unique[u][ci][ky][kx] += sum_G part[G](tap, ci, u) + (u < h/2) sum_G part[G](x-mirrored tap, ci, U+u)
 // 64 outputs per block; the four waves split the slab range and combine through LDS (deterministic order)
 struct WfJob {
   int K, U, Cin, Cin0, CB0, CinP, CoutP, Cout, symh, G, first_block;
@@ -69,53 +69,64 @@ constexpr int WF_MAX = 32;
 struct WfTable { int n; WfJob j[WF_MAX]; };
 
 __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock) {
+  // outputs are enumerated in slab order [tap][chunk][u][16] (coalesced reads of every slab), then the bias entries
   const int K = g.K, KK = K * K;
-  const int cols = g.CinP * KK + 1;
-  const size_t slab = (size_t)g.CoutP * cols;
-  const size_t nW = (size_t)g.U * g.Cin * KK;
+  const int nch = wg_chunks(g.CinP);
+  const size_t slab = wg_slab_floats(g.CoutP, g.CinP, KK);
+  const size_t nW = (size_t)KK * nch * g.U * 16;
   const size_t total = nW + g.Cout;
   const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t i = (size_t)lblock * 64 + e;
   __shared__ float red[4][64];
   float s = 0.f;
+  long dst = -1;                  // index into dw (>= 0), or -2 - co for the bias
   if (i < total) {
     size_t o1, o2 = 0;
-    bool two = false;
+    bool two = false, live = true;
     if (i < nW) {
-      int kx = (int)(i % K);
-      size_t r = i / K;
-      int ky = (int)(r % K); r /= K;
-      int ci = (int)(r % g.Cin);
-      int u = (int)(r / g.Cin);
-      int cip = cin_padded_index(ci, g.Cin0, g.CB0);
-      o1 = (size_t)u * cols + (size_t)cip * KK + ky * K + kx;
-      if (u < g.symh / 2) { two = true; o2 = (size_t)(g.U + u) * cols + (size_t)cip * KK + ky * K + (K - 1 - kx); }
+      int cl = (int)(i & 15);
+      size_t r = i >> 4;
+      int u = (int)(r % g.U); r /= g.U;
+      int chunk = (int)(r % nch);
+      int tap = (int)(r / nch);
+      int cip = chunk * 16 + cl;
+      int ci = cip < g.CB0 * 8 ? cip : g.Cin0 + (cip - g.CB0 * 8);
+      live = cip < g.CB0 * 8 ? cip < g.Cin0 : ci < g.Cin;
+      int ky = tap / K, kx = tap - ky * K;
+      o1 = wg_index(tap, cip, u, g.CoutP, nch);
+      if (u < g.symh / 2) { two = true; o2 = wg_index(ky * K + (K - 1 - kx), cip, g.U + u, g.CoutP, nch); }
+      dst = ((long)u * g.Cin + ci) * KK + tap;
     } else {
-      o1 = (size_t)(i - nW) * cols + (size_t)g.CinP * KK;
+      o1 = (size_t)KK * nch * g.CoutP * 16 + (i - nW);
+      dst = -2 - (long)(i - nW);
     }
-    const float* part = g.part;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int G = w;
-    for (; G + 12 < g.G; G += 16) {
-      a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + 4) * slab + o1];
-      a2 += part[(size_t)(G + 8) * slab + o1]; a3 += part[(size_t)(G + 12) * slab + o1];
-      if (two) {
-        a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + 4) * slab + o2];
-        a2 += part[(size_t)(G + 8) * slab + o2]; a3 += part[(size_t)(G + 12) * slab + o2];
+    if (live) {
+      const float* part = g.part;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int G = w;
+      for (; G + 12 < g.G; G += 16) {
+        a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + 4) * slab + o1];
+        a2 += part[(size_t)(G + 8) * slab + o1]; a3 += part[(size_t)(G + 12) * slab + o1];
+        if (two) {
+          a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + 4) * slab + o2];
+          a2 += part[(size_t)(G + 8) * slab + o2]; a3 += part[(size_t)(G + 12) * slab + o2];
+        }
       }
+      for (; G < g.G; G += 4) {
+        a0 += part[(size_t)G * slab + o1];
+        if (two) a0 += part[(size_t)G * slab + o2];
+      }
+      s = (a0 + a1) + (a2 + a3);
+    } else {
+      dst = -1;
     }
-    for (; G < g.G; G += 4) {
-      a0 += part[(size_t)G * slab + o1];
-      if (two) a0 += part[(size_t)G * slab + o2];
-    }
-    s = (a0 + a1) + (a2 + a3);
   }
   red[w][e] = s;
   __syncthreads();
-  if (w == 0 && i < total) {
+  if (w == 0 && dst != -1) {
     float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    if (i < nW) { if (g.dw) g.dw[i] += r; }
-    else if (g.db) g.db[i - nW] += r;
+    if (dst >= 0) { if (g.dw) g.dw[dst] += r; }
+    else if (g.db) g.db[-2 - dst] += r;
   }
 }
 
@@ -133,7 +144,7 @@ int wf_fill(const mc_conv_desc* d, const void* partials, float* dw, float* db, W
   if (!partials || (!dw && !db)) return MC_EINVAL;
   j.K = g.K; j.U = g.U; j.Cin = g.Cin; j.Cin0 = g.Cin0; j.CB0 = g.CB0; j.CinP = g.CinP; j.CoutP = g.CoutP; j.Cout = g.Cout;
   j.symh = g.sym_h; j.G = g.wgrad_G; j.part = (const float*)partials; j.dw = dw; j.db = db;
-  size_t total = (size_t)g.U * g.Cin * g.K * g.K + g.Cout;
+  size_t total = (size_t)g.K * g.K * wg_chunks(g.CinP) * g.U * 16 + g.Cout;
   blocks = (int)((total + 63) / 64);
   return MC_OK;
 }
@@ -202,7 +213,7 @@ int mc_conv2d(const mc_conv_desc* d, const void* x0, const void* x1, const void*
 size_t mc_wgrad_partial_bytes(const mc_conv_desc* d) {
   ConvGeom g;
   if (geom_for(d, g)) return 0;
-  return (size_t)g.wgrad_G * g.CoutP * ((size_t)g.CinP * g.K * g.K + 1) * sizeof(float);
+  return (size_t)g.wgrad_G * wg_slab_floats(g.CoutP, g.CinP, g.K * g.K) * sizeof(float);
 }
 
 int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const void* dy, void* partials,

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
 //
 // Block (G, chunk, co-group): loops over (image, 16x32-pixel tile) work items; wave w owns taps w, w+4, ...
 // (7/6/6/6 of 25) for NTW co-tiles; wave 3 also accumulates the bias gradient through an all-ones B fragment.
-// Partials: [G][CoutP][CinP*K*K + 1] f32, combined deterministically by k_wgrad_finalize.
+// Partials: [G] slabs (layout: wg_index in conv_common.h), combined deterministically by k_wgrad_finalize.
 // ------------------------------------------------------------------------------------------------
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s lds_v4s;
@@ -518,10 +518,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
       }
     }
   }
-  // ---- write this block's partial slab
-  const int cols = g.CinP * KK + 1;
-  float* pb = part + (size_t)bid * g.CoutP * cols;
-  const int cip = chunk * 16 + (lane & 15);
+  // ---- write this block's partial slab: P[tap][chunk][co][16] (+ bias); a 16-lane group stores 64 contiguous bytes
+  const int nch = wg_chunks(g.CinP);
+  float* pb = part + (size_t)bid * wg_slab_floats(g.CoutP, g.CinP, KK);
 #pragma unroll
   for (int ti = 0; ti < NTAP; ++ti) {
     int tap = wave + 4 * ti;
@@ -532,9 +531,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
         int co = (cog * NTW + t) * 16 + gq * 4 + r;
         if (co >= g.CoutP) continue;
         if (tap < KK) {
-          if (cip < g.CinP) pb[(size_t)co * cols + (size_t)cip * KK + tap] = acc[ti][t][r];
+          pb[((size_t)(tap * nch + chunk) * g.CoutP + co) * 16 + (lane & 15)] = acc[ti][t][r];
         } else if (do_bias && ti == NTAP - 1 && (lane & 15) == 0) {
-          pb[(size_t)co * cols + (size_t)g.CinP * KK] = acc[ti][t][r];
+          pb[(size_t)KK * nch * g.CoutP * 16 + co] = acc[ti][t][r];
         }
       }
   }

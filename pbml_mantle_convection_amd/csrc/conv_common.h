@@ -1,5 +1,6 @@
 // Geometry shared by the f32 and bf16 convolution paths.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 struct ConvGeom {
@@ -14,6 +15,23 @@ struct ConvGeom {
   int dtype;
   int out_f32;
 };
+
+// filter-gradient partial slab (one per reduction workgroup): P[tap][16-channel input chunk][co][16] f32 followed by
+// the bias gradient [CoutP].  The 16 input channels of a chunk are the fastest axis so that the 16-lane groups of
+// the MFMA accumulator layout store 64 contiguous bytes (a [co][ci][tap] layout scattered 4-byte stores 100 B
+// apart and cost ~100 us per deep-level layer).
+static __host__ __device__ inline int wg_chunks(int CinP) { return (CinP + 15) / 16; }
+static __host__ __device__ inline size_t wg_slab_floats(int CoutP, int CinP, int KK) {
+  return (size_t)KK * wg_chunks(CinP) * CoutP * 16 + CoutP;
+}
+static __host__ __device__ inline size_t wg_index(int tap, int cip, int co, int CoutP, int nch) {
+  return ((size_t)(tap * nch + (cip >> 4)) * CoutP + co) * 16 + (cip & 15);
+}
+static inline long wgrad_target_blocks() {
+  static long v = 0;
+  if (!v) { const char* e = getenv("MC_WGRAD_BLOCKS"); v = e ? atol(e) : 768; if (v < 16) v = 16; }
+  return v;
+}
 
 // fills g from d; returns MC_OK or an error code.  tile_h/tile_w = output tile of the kernel family.
 static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvGeom& g) {
@@ -44,7 +62,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   if (g.out_f32 && (d->c_out > 16 || d->c_out_split != 0)) return MC_EUNSUPPORTED;
   // number of partial slabs of the filter-gradient reduction: enough workgroups to fill the chip
   // (~1024 with the other grid dimensions), bounded by 64 MiB of partials and by the work available
-  long slab = (long)g.CoutP * ((long)g.CinP * g.K * g.K + 1) * 4;
+  long slab = (long)wg_slab_floats(g.CoutP, g.CinP, g.K * g.K) * 4;
   long cap = (64L << 20) / slab;
   if (cap < 32) cap = 32;
   long G, work;
@@ -52,7 +70,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
     int ntiles = (g.Cout + 15) / 16;
     int ntw = (ntiles % 2 == 0) ? 2 : 1;
     long other = (long)((g.CBin + 1) / 2) * ((ntiles + ntw - 1) / ntw);
-    G = (768 + other - 1) / other;
+    G = (wgrad_target_blocks() + other - 1) / other;
     if (G < 16) G = 16;
     work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
   } else {

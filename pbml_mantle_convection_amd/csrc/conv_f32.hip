@@ -182,16 +182,16 @@ __global__ __launch_bounds__(256) void k_wgrad_direct_f32(ConvGeom g, const floa
       for (int p = 0; p < TS * TS; ++p) bacc += dys[p][co];
     }
   }
-  const int cols = g.CinP * K * K + 1;
-  float* pb = part + (size_t)blockIdx.x * g.CoutP * cols;
+  const int nch = wg_chunks(g.CinP);
+  float* pb = part + (size_t)blockIdx.x * wg_slab_floats(g.CoutP, g.CinP, K * K);
   if (wthread) {
     int cig = cb * 8 + ci;
 #pragma unroll
     for (int co = 0; co < 16; ++co)
-      if (co0 + co < g.CoutP) pb[(size_t)(co0 + co) * cols + (size_t)cig * K * K + tap] = acc[co];
+      if (co0 + co < g.CoutP) pb[wg_index(tap, cig, co0 + co, g.CoutP, nch)] = acc[co];
   } else if (bthread) {
     int co = co0 + t - 8 * K * K;
-    if (co < g.CoutP) pb[(size_t)co * cols + (size_t)g.CinP * K * K] = bacc;
+    if (co < g.CoutP) pb[(size_t)K * K * nch * g.CoutP * 16 + co] = bacc;
   }
 }
 
