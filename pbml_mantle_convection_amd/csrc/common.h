@@ -150,6 +150,25 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// 16 per-lane values -> 16 wave totals with 17 shuffles instead of 96: at every step a lane keeps the half of its
+// values selected by one lane-index bit and adds the partner's copy of that half.  On return the lanes with
+// (lane & 3) == 0 hold the wave total of value index idx (each of the 16 indices on exactly one such lane).
+__device__ __forceinline__ float wave_sum16(const float (&s)[16], int lane, int& idx) {
+  float t[8], u[4], v[2], w;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t[k] = (b5 ? s[8 + k] : s[k]) + __shfl_xor(b5 ? s[k] : s[8 + k], 32, 64);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u[k] = (b4 ? t[4 + k] : t[k]) + __shfl_xor(b4 ? t[k] : t[4 + k], 16, 64);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) v[k] = (b3 ? u[2 + k] : u[k]) + __shfl_xor(b3 ? u[k] : u[2 + k], 8, 64);
+  w = (b2 ? v[1] : v[0]) + __shfl_xor(b2 ? v[0] : v[1], 4, 64);
+  w += __shfl_xor(w, 2, 64);
+  w += __shfl_xor(w, 1, 64);
+  idx = (b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0);
+  return w;
+}
+
 // ---- gradient sources of an activated tensor (see mc_grad_src) ---------------------------------
 // candidates of padded coordinates that fold onto interior coordinate i: writes up to 3 padded
 // indices (already offset by +p, i.e. indices into the padded buffer) and returns the count.

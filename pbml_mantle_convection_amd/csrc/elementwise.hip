@@ -221,7 +221,7 @@ __global__ void k_avgpool(const T* __restrict__ x, int C8, int H, int W, int f, 
 // =================================================================================================
 // phase 1: partial[n][blk][c][2] = (sum dz, sum dz * yhat) over this block's pixels
 template <typename T>
-__global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
+__global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
                                                        mc_grad_src g1, float* __restrict__ part, int CP) {
   const int n = blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   float sc[8], sh[8], mean[8], rstd[8];
@@ -253,10 +253,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(GnArgs a, const T* __rest
     }
   }
   __shared__ float red[4][16];
+  {
+    float s[16];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float r1 = wave_sum(s1[j]), r2 = wave_sum(s2[j]);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][j * 2] = r1; red[threadIdx.x >> 6][j * 2 + 1] = r2; }
+    for (int j = 0; j < 8; ++j) { s[2 * j] = s1[j]; s[2 * j + 1] = s2[j]; }
+    int idx;
+    float r = wave_sum16(s, threadIdx.x & 63, idx);
+    if ((threadIdx.x & 3) == 0) red[threadIdx.x >> 6][idx] = r;
   }
   __syncthreads();
   if (threadIdx.x < 16) {
@@ -321,10 +324,10 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
         acc[q * 4 + 0] += v.x; acc[q * 4 + 1] += v.y; acc[q * 4 + 2] += v.z; acc[q * 4 + 3] += v.w;
       }
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float r = wave_sum(acc[j]);
-      if ((threadIdx.x & 63) == 0) fsum[threadIdx.x >> 6][j] = r;
+    {
+      int idx;
+      float r = wave_sum16(acc, threadIdx.x & 63, idx);
+      if ((threadIdx.x & 3) == 0) fsum[threadIdx.x >> 6][idx] = r;
     }
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < 16) {

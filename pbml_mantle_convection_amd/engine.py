@@ -266,7 +266,9 @@ class Engine:
         self.shape = None
         self._tables = {}
         self.fused_gn_bwd = os.environ.get("MANTLE_FUSED_GN_BWD", "0") != "0"   # A/B on MI355X: the fused form is 0.45 ms/step slower (131 VGPRs)
-        self.overlap_wgrad = os.environ.get("MANTLE_OVERLAP_WGRAD", "0") != "0"   # A/B on MI355X: no gain, every kernel already fills the chip
+        # filter-gradient kernels on a second stream: 0 = never, 1 = every layer, 2 = only layers of <= 128 x 128 pixels
+        # (their launches are latency-bound and leave most of the chip idle)
+        self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "1"))   # A/B on MI355X: 1 is 0.25 ms/step faster than 0, 2 is no gain
 
     # -------------------------------------------------------------- planning
     def configure(self, N: int, H: int, W: int, device):
@@ -455,8 +457,7 @@ class Engine:
         # so they run on `side` while `main` continues with the input gradient and the next layer's GroupNorm
         # backward.  dY alternates between two buffers; main waits for the side stream before reusing one.
         main = torch.cuda.current_stream()
-        side = self.side if self.overlap_wgrad else main
-        side.wait_stream(main)
+        self.side.wait_stream(main)
         wg_done = [None, None]
         k = 0
         fo = T[self.plan[-1]["node"].out]
@@ -519,6 +520,8 @@ class Engine:
                            self.mc_dtype, g0, g1, L.ptr(dY), st)
             x0 = L.ptr(srcs[0].buf)
             x1 = L.ptr(srcs[1].buf) if len(srcs) > 1 else None
+            side = self.side if (self.overlap_wgrad == 1 or (self.overlap_wgrad == 2 and o.H * o.W <= 128 * 128)) else main
+            wg_done[k & 1] = None
             if side is not main:
                 ev = torch.cuda.Event()
                 ev.record(main)                           # dY of this layer is complete
@@ -541,7 +544,7 @@ class Engine:
                         # adjoint of the padding: fold the halo onto the interior once, consumers read at an offset
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
-        main.wait_stream(side)
+        main.wait_stream(self.side)
         # one launch combines every layer's partial slabs, folds mirrored filters and accumulates into the gradients
         n = len(self.convs)
         descs = (L.ConvDesc * n)(*[e["desc"] for e in self.convs])
