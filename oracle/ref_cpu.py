@@ -60,6 +60,31 @@ def activation(name: str, t: Tensor) -> Tensor:
     return _ACTS[name](t)
 
 
+# The device's bf16 mode evaluates GELU / GELU' with odd minimax polynomials on |z| <= 4 (csrc/common.h
+# gelu_cdf_poly / gelu_grad_poly; the fp32 mode uses erff/expf).  Restated here so that the storage-rounding
+# emulation below can reproduce the device's rounding decisions, and so that a CPU test pins their accuracy.
+GELU_CDF_POLY = (3.989080743e-01, -6.630133159e-02, 9.743199580e-03, -1.069904774e-03, 8.376238344e-05, -4.337137479e-06, 1.308749780e-07, -1.722451212e-09)
+GELU_GRAD_POLY = (7.976932610e-01, -2.647867851e-01, 5.822368255e-02, -8.560219625e-03, 8.634741876e-04,
+                  -5.865809327e-05, 2.541382519e-06, -6.288852653e-08, 6.715542261e-10)
+
+
+def _odd_poly(t: Tensor, coef) -> Tensor:
+    zc = t.clamp(-4.0, 4.0)
+    w = zc * zc
+    p = torch.full_like(t, coef[-1])
+    for ck in coef[-2::-1]:
+        p = p * w + ck
+    return zc * p + 0.5
+
+
+def gelu_bf16_mode(t: Tensor) -> Tensor:
+    return t * _odd_poly(t, GELU_CDF_POLY).clamp(0.0, 1.0)
+
+
+def gelu_grad_bf16_mode(t: Tensor) -> Tensor:
+    return _odd_poly(t, GELU_GRAD_POLY)
+
+
 def torch_pad_mode(r_p: str) -> str:
     """'zeros' is spelled 'constant' for F.pad (pytorch_networks_convae.py:732-735)."""
     return "constant" if r_p == "zeros" else r_p
@@ -193,12 +218,14 @@ def unet_features(sd, x, levels, repeats, act, r_p, use_symm) -> Tensor:
     return (y - y.mean(dim=(2, 3), keepdim=True))[..., 3:-3]
 
 
-def unet_features_quantised(sd, x, levels, repeats, act, r_p, use_symm, q) -> Tensor:
+def unet_features_quantised(sd, x, levels, repeats, act, r_p, use_symm, q, device_gelu=True) -> Tensor:
     """unet_features with the storage rounding of the device's bf16 mode emulated: `q` (e.g. a bf16
     round-trip) is applied wherever the engine stores a tensor — packed input, filter banks, raw conv
     outputs (GroupNorm statistics are taken BEFORE that rounding, from the f32 accumulators), activated
-    outputs, pooled and upsampled tensors; the last conv's output stays f32.  Forward only (tests)."""
+    outputs, pooled and upsampled tensors; the last conv's output stays f32; GELU is the bf16 mode's
+    polynomial unless device_gelu=False.  Forward only (tests)."""
     mode = torch_pad_mode(r_p)
+    act_fn = gelu_bf16_mode if (device_gelu and act == "gelu") else (lambda t: activation(act, t))
 
     def conv(xin, w, b):
         return conv2d_same(xin, q(w), b, r_p)
@@ -223,7 +250,7 @@ def unet_features_quantised(sd, x, levels, repeats, act, r_p, use_symm, q) -> Te
             z = z * sd[gn_prefix + "weight"].view(1, -1, 1, 1) + sd[gn_prefix + "bias"].view(1, -1, 1, 1)
         else:
             z = yq
-        a = activation(act, z)
+        a = act_fn(z)
         return q(a), a
 
     x = F.pad(x, (3, 3, 0, 0)) if mode == "constant" else F.pad(x, (3, 3, 0, 0), mode=mode)

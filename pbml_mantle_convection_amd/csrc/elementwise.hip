@@ -180,11 +180,9 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
           float v[8];
           size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
           V8<T>::ld(y + idx, v);
+          act_fwd8<FastMath<T>::value>(v, sc, sh, act, v);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            v[j] = act_fwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], act);
-            acc[j] += v[j];
-          }
+          for (int j = 0; j < 8; ++j) acc[j] += v[j];
           V8<T>::st(out + idx, v);
         }
       }
@@ -245,9 +243,11 @@ __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __r
     V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
     grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
     grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+    float ga[8];
+    act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, ga);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
+      float dz = da[j] * ga[j];
       s1[j] += dz;
       s2[j] += dz * (v[j] - mean[j]) * rstd[j];
     }
@@ -368,8 +368,6 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
       } else { ga[j] = 1.f; rstd[j] = 1.f; }
     }
   }
-  // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over
-  // >= 8 vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s)
   // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over several
   // vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s).  (A 4-way manual batching
   // of the loads was tried and was SLOWER: 131 VGPRs cut the occupancy of this streaming kernel.)
@@ -381,9 +379,11 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
     V8<T>::ld(y + idx, v);
     grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
     grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+    float gz[8];
+    act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float dz = da[j] * act_bwd_t<FastMath<T>::value>(v[j] * sc[j] + sh[j], a.act);
+      float dz = da[j] * gz[j];
       if (a.post == MC_POST_GN_ACT) {
         float yh = (v[j] - mean[j]) * rstd[j];
         o[j] = rstd[j] * (dz * ga[j] - m1[j] - yh * m2[j]);

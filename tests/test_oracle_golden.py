@@ -295,3 +295,19 @@ def test_momentum_residual_manufactured_solution():
                                      torch.ones(1, dtype=f64), inv_h=1.0 / h)
         errs.append(float(torch.maximum(rx.abs().max(), ry.abs().max())))
     assert errs[1] < errs[0] / 3.0 and errs[2] < errs[1] / 3.0, errs
+
+
+def test_bf16_mode_gelu_polynomials_are_within_bf16_rounding():
+    """The device's bf16 mode replaces erf by an odd polynomial (csrc/common.h); the error must stay far below the
+    bf16 rounding (2^-9 relative) of the tensors it produces, also when evaluated in float32."""
+    z = torch.linspace(-12.0, 12.0, 480001, dtype=torch.float64)
+    gelu = torch.nn.functional.gelu(z)
+    cdf = 0.5 * (1.0 + torch.erf(z / 2.0 ** 0.5))
+    grad = cdf + z * torch.exp(-0.5 * z * z) / (2.0 * torch.pi) ** 0.5
+    for dt in (torch.float64, torch.float32):
+        zz = z.to(dt)
+        assert float((O.gelu_bf16_mode(zz).double() - gelu).abs().max()) < 2e-4
+        assert float((O.gelu_grad_bf16_mode(zz).double() - grad).abs().max()) < 6e-4
+    # exact at the origin, monotone saturation outside the fitted interval
+    assert float(O.gelu_bf16_mode(torch.zeros(1))) == 0.0
+    assert float(O.gelu_grad_bf16_mode(torch.zeros(1))) == 0.5
