@@ -16,6 +16,7 @@
 // writes 16-byte CB8 vectors.  The input gradient reuses the kernel on the zero-padded (k-1) domain
 // with the rotated / transposed bank.
 #include "conv_common.h"
+#include <type_traits>
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -114,6 +115,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   static_assert(IN_ITERS <= CHUNK_CB * PER_CB, "");
   v4u rin[CHUNK_CB][PER_CB];
   int s_rc[PER_CB];                                             // window (row, col) of this thread's slot; bit 31: dead
+  unsigned s_off[PER_CB];                                       // byte offset of the slot inside an interior tile's window
+  int s_lds[PER_CB];                                            // LDS slot (negative: dead)
 #pragma unroll
   for (int it = 0; it < PER_CB; ++it) {
     int i = threadIdx.x + it * 256;
@@ -121,6 +124,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     if (!live) i = TIH * TIW - 1;
     int r = i / TIW, c = i - r * TIW;
     s_rc[it] = (live ? 0 : (1 << 31)) | (r << 15) | c;
+    s_off[it] = (unsigned)(r * g.W + c) * 16u;
+    s_lds[it] = live ? r * TIW + c : -1;
   }
   auto prefetch = [&](int t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
-    const int org = (ty0 - g.pad) * g.W + (tx0 - g.pad);
+    const unsigned org16 = (unsigned)((ty0 - g.pad) * g.W + (tx0 - g.pad)) * 16u;   // wraps for border tiles (unused there)
 #pragma unroll
     for (int cb = 0; cb < CHUNK_CB; ++cb) {
       const int gcb = ck * CHUNK_CB + cb;
@@ -142,11 +147,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, gcb < g.CBin ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll
       for (int it = 0; it < PER_CB; ++it) {
-        int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
         unsigned off;
         if (interior) {
-          off = (unsigned)(org + r * g.W + c) * 16u;
+          off = org16 + s_off[it];
         } else {
+          int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
           bool oky, okx;
           int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
           int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
@@ -161,10 +166,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     for (int cb = 0; cb < CHUNK_CB; ++cb)
 #pragma unroll
       for (int it = 0; it < PER_CB; ++it)
-        if (s_rc[it] >= 0) {
-          int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
-          in_s[cb * PLANE + r * TIW + c] = make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]);
-        }
+        if (s_lds[it] >= 0)
+          in_s[cb * PLANE + s_lds[it]] = make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]);
   };
   // the bank slice changes only with the chunk: single-chunk layers (65 % of the FLOPs) stage it once
   auto stage_weights = [&](int ck) {
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){bv[tt][0], bv[tt][1], bv[tt][2], bv[tt][3]};   // bias folded in
     }
     if (!PREFETCH) prefetch(t);
     __syncthreads();                                            // LDS free: previous MFMA loop done
@@ -276,11 +279,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     const int wi = bid + jitem * gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
-    float s1[NT][4], s2[NT][4];
+    f32x2 s1[NT][2], s2[NT][2];                                  // per-lane (sum, sum of squares) of channel pairs
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[tt][r] = 0.f; s2[tt][r] = 0.f; }
+      for (int h = 0; h < 2; ++h) { s1[tt][h] = (f32x2){0.f, 0.f}; s2[tt][h] = (f32x2){0.f, 0.f}; }
     // output pointers of this lane's first M-tile per N-tile (bytes); later M-tiles are constant strides away
     const int oy0 = ty0 + (wave * MT) / MTILES_X, ox0 = tx0 + ((wave * MT) % MTILES_X) * 16 + m;
     char* dst0[NT];
@@ -297,42 +300,53 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
         dst0[tt] = reinterpret_cast<char*>(y0) + (cb8_index(n, cbc, oy0, ox0, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo) + (gq & 1) * 4) * esz;
     }
     const size_t row_bytes = (size_t)g.Wo * 8 * (OUT_F32 ? 4 : 2);
+    // tiles that lie completely inside the output skip every bounds test (wave-uniform branch); the VALU work of this
+    // epilogue, not the MFMA loop or the memory system, bounded the single-N-tile kernel (PMC: 590 VALU / 104 MFMA per wave-tile)
+    auto emit = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int oy = oy0 + i / MTILES_X, ox = ox0 + (i % MTILES_X) * 16;         // C/D: col = lane & 15 = pixel
-      const bool inb = oy < g.Ho && ox < g.Wo;
-      const size_t off = (size_t)(i / MTILES_X) * row_bytes + (size_t)(i % MTILES_X) * 16 * 8 * (OUT_F32 ? 4 : 2);
+      for (int i = 0; i < MT; ++i) {
+        const int oy = oy0 + i / MTILES_X, ox = ox0 + (i % MTILES_X) * 16;         // C/D: col = lane & 15 = pixel
+        const bool inb = FULL || (oy < g.Ho && ox < g.Wo);
+        const size_t off = (size_t)(i / MTILES_X) * row_bytes + (size_t)(i % MTILES_X) * 16 * 8 * (OUT_F32 ? 4 : 2);
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][tt][r] + bv[tt][r];
-          if (inb) { s1[tt][r] += v[r]; s2[tt][r] += v[r] * v[r]; }
-        }
-        if (inb && cobok[tt]) {
-          if (OUT_F32) {
-            *reinterpret_cast<float4*>(dst0[tt] + off) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 pk;
-            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2*>(dst0[tt] + off) = pk;
+        for (int tt = 0; tt < NT; ++tt) {
+          const f32x2 v01 = (f32x2){acc[i][tt][0], acc[i][tt][1]}, v23 = (f32x2){acc[i][tt][2], acc[i][tt][3]};
+          if (inb) {
+            s1[tt][0] += v01; s1[tt][1] += v23;
+            s2[tt][0] = pk_fma(v01, v01, s2[tt][0]); s2[tt][1] = pk_fma(v23, v23, s2[tt][1]);
+          }
+          if (inb && cobok[tt]) {
+            if (OUT_F32) {
+              *reinterpret_cast<float4*>(dst0[tt] + off) = make_float4(v01.x, v01.y, v23.x, v23.y);
+            } else {
+              uint2 pk;
+              pk.x = (uint32_t)f2bf(v01.x) | ((uint32_t)f2bf(v01.y) << 16);
+              pk.y = (uint32_t)f2bf(v23.x) | ((uint32_t)f2bf(v23.y) << 16);
+              *reinterpret_cast<uint2*>(dst0[tt] + off) = pk;
+            }
           }
         }
       }
-    }
+    };
+    if (ty0 + TH <= g.Ho && tx0 + TW <= g.Wo) emit(std::true_type{}); else emit(std::false_type{});
     if (part) {
-      // reduce over the 16 pixel lanes of each 16-lane group; lane m == 0 of group gq owns channels 4 gq .. 4 gq + 3
+      // sum over the 16 pixel lanes of each 16-lane group with a halving butterfly (8 shuffles for the 8 values of an
+      // N-tile instead of 32): afterwards lane m of a group holds the group total of value index m >> 1 (m even)
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt)
+      for (int tt = 0; tt < NT; ++tt) {
+        float q8[8] = {s1[tt][0].x, s2[tt][0].x, s1[tt][0].y, s2[tt][0].y, s1[tt][1].x, s2[tt][1].x, s1[tt][1].y, s2[tt][1].y};
+        const bool b3 = m & 8, b2 = m & 4, b1 = m & 2;
+        float q4[4], q2[2], q1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float a = s1[tt][r], b = s2[tt][r];
+        for (int k = 0; k < 4; ++k) q4[k] = (b3 ? q8[4 + k] : q8[k]) + __shfl_xor(b3 ? q8[k] : q8[4 + k], 8, 64);
 #pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-          if (m == 0) { red[wave][(tt * 16 + gq * 4 + r) * 2] = a; red[wave][(tt * 16 + gq * 4 + r) * 2 + 1] = b; }
-        }
+        for (int k = 0; k < 2; ++k) q2[k] = (b2 ? q4[2 + k] : q4[k]) + __shfl_xor(b2 ? q4[k] : q4[2 + k], 4, 64);
+        q1 = (b1 ? q2[1] : q2[0]) + __shfl_xor(b1 ? q2[0] : q2[1], 2, 64);
+        q1 += __shfl_xor(q1, 1, 64);
+        // value index = 4 b3 + 2 b2 + b1 = (channel r = idx >> 1, idx & 1 = sum / sum of squares)
+        if ((m & 1) == 0) red[wave][(tt * 16 + gq * 4) * 2 + (m >> 1)] = q1;
+      }
       __syncthreads();
       if (threadIdx.x < NT * 32) {
         int co = ntile0 * 16 + (threadIdx.x >> 1);
