@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
 
   const int grp = blockIdx.y;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar
   const int m = lane & 15, gq = lane >> 4;
   const int ntile0 = grp * NT;                                  // first global N-tile of this block
   const int ntiles_total = gridDim.y * NT;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   __shared__ uint4 ds[NTW * 2 * DPS];
   const int chunk = blockIdx.y, cog = blockIdx.z;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tap offsets live in SGPRs
   const int q = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
   // per-lane short offsets (2-byte units) inside a plane pair for pixel 8g + q of a row start
   const int lane_x = ((p >> 1) * XPS + 8 * gq + q) * 8 + (p & 1) * 4;
@@ -420,6 +420,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     int tap = wave + 4 * ti;
     toff[ti] = tap < KK ? ((tap / K) * TIW + (tap % K)) * 8 : -1;
   }
+  const short* xtap[NTAP];                                      // this lane's x-tile address per tap (row 0)
+#pragma unroll
+  for (int ti = 0; ti < NTAP; ++ti) xtap[ti] = xs_s + lane_x + max(toff[ti], 0);
   // static staging slots of this thread
   int x_rc[X_ITERS];
 #pragma unroll
@@ -511,16 +514,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     commit();
     __syncthreads();
     if (wi + (int)gridDim.x < work) prefetch(wi + gridDim.x);   // next work item's loads retire under the MFMA loop
-#pragma unroll 1
+#ifndef MC_WGRAD_ROW_UNROLL
+#define MC_WGRAD_ROW_UNROLL 2   /* A/B on MI355X: 2 and 4 equal within noise, 16 thrashes the instruction cache (70x slower) */
+#endif
+    // rows unrolled so that the row offsets become instruction immediates (the loop was VALU-issue bound on address adds)
+#pragma unroll MC_WGRAD_ROW_UNROLL
     for (int row = 0; row < WTH; ++row) {
       bf16x8 a[NTW];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) a[t] = tr_frag(ds_s + (t * 2 * DPS + row * WTW) * 8 + lane_d);
-      const short* xrow = xs_s + row * TIW * 8 + lane_x;
+      for (int t = 0; t < NTW; ++t) a[t] = tr_frag(ds_s + lane_d + (t * 2 * DPS + row * WTW) * 8);
 #pragma unroll
       for (int ti = 0; ti < NTAP; ++ti) {
         if (toff[ti] >= 0) {
-          bf16x8 b = tr_frag(xrow + toff[ti]);
+          bf16x8 b = tr_frag(xtap[ti] + row * TIW * 8);
 #pragma unroll
           for (int t = 0; t < NTW; ++t) acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[ti][t], 0, 0, 0);
         }
