@@ -66,11 +66,16 @@ __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad,
 // pixel, row = 4*(lane>>4)+reg = channel): exactly 8 contiguous bytes of the CB8 output vector.  The
 // epilogue therefore stores straight from registers (no LDS transpose, no extra barriers).
 // ------------------------------------------------------------------------------------------------
+#ifdef MC_EXP_NOSYNC   /* timing experiment only: racy */
+#define MC_SYNC() do {} while (0)
+#else
+#define MC_SYNC() __syncthreads()
+#endif
 template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false>
 #ifndef MC_CONV_WAVES
 #define MC_CONV_WAVES 2
 #endif
-__global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_conv_mfma_bf16(
+__global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_conv_mfma_bf16(
     ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ bank,
     const float* __restrict__ bias, bf16_t* __restrict__ y0, bf16_t* __restrict__ y1, float* __restrict__ part,
     int n_groups) {
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   constexpr int PLANE = (TIH * TIW + 15) / 16 * 16;           // 16-byte slots per channel-block plane
   constexpr int STEPS = KSteps<K>::steps;
   constexpr int MTILES_X = TW / 16;
-  static_assert(TH * MTILES_X == 4 * MT, "tile / wave decomposition mismatch");
+  constexpr int WAVES = TH * MTILES_X / MT, NTHR = 64 * WAVES;   // each wave owns MT 16-pixel M-tiles of the output tile
+  static_assert(TH * MTILES_X == WAVES * MT && (WAVES == 4 || WAVES == 8), "tile / wave decomposition mismatch");
   constexpr int IN_SLOTS = CHUNK_CB * PLANE;
   // NT == 1: the bank slice (13 KiB) is staged in LDS once per chunk.  NT > 1 (deep, channel-heavy layers): the slice
   // would be 27-53 KiB per chunk and re-staging it dominated the per-workgroup critical path, so B fragments are read
@@ -90,10 +96,10 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   constexpr int W_SLOTS = WGLOBAL ? 0 : STEPS * NT * 64;
   static_assert(!OUT_F32 || NT == 1, "f32 output is for the single-N-tile configuration");
   constexpr int IN_ELEMS = CHUNK_CB * TIH * TIW;
-  constexpr int IN_ITERS = (IN_ELEMS + 255) / 256;
-  constexpr int W_ITERS = WGLOBAL ? 1 : (W_SLOTS + 255) / 256;
+  constexpr int IN_ITERS = (IN_ELEMS + NTHR - 1) / NTHR;
+  constexpr int W_ITERS = WGLOBAL ? 1 : (W_SLOTS + NTHR - 1) / NTHR;
   __shared__ uint4 lds[IN_SLOTS + (WGLOBAL ? 1 : W_SLOTS)];
-  __shared__ float red[4][NT * 16 * 2];
+  __shared__ float red[WAVES][NT * 16 * 2];
   uint4* in_s = lds;
   uint4* w_s = lds + IN_SLOTS;
 
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   // Staging loads are raw buffer loads: one descriptor per (image, source tensor); an out-of-range offset
   // returns zeros in hardware, which IS the zero padding / missing channel block — no branches, no selects,
   // so the loads of a stage issue back to back.  Iterations are split per channel block (descriptor is uniform).
-  constexpr int PER_CB = (TIH * TIW + 255) / 256;
+  constexpr int PER_CB = (TIH * TIW + NTHR - 1) / NTHR;
   static_assert(IN_ITERS <= CHUNK_CB * PER_CB, "");
   v4u rin[CHUNK_CB][PER_CB];
   int s_rc[PER_CB];                                             // window (row, col) of this thread's slot; bit 31: dead
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   int s_lds[PER_CB];                                            // LDS slot (negative: dead)
 #pragma unroll
   for (int it = 0; it < PER_CB; ++it) {
-    int i = threadIdx.x + it * 256;
+    int i = threadIdx.x + it * NTHR;
     bool live = i < TIH * TIW;
     if (!live) i = TIH * TIW - 1;
     int r = i / TIW, c = i - r * TIW;
@@ -157,7 +163,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
           int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
           off = (oky && okx) ? (unsigned)(sy * g.W + sx) * 16u : 0xFFFFFFF0u;
         }
+#ifdef MC_EXP_NOLOAD   /* timing experiment only: wrong results */
+        rin[cb][it] = (v4u){off, off, off, off};
+#else
         rin[cb][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+#endif
       }
     }
   };
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     uint4 rw[W_ITERS];
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it) {
-      int i = min((int)threadIdx.x + it * 256, W_SLOTS - 1);
+      int i = min((int)threadIdx.x + it * NTHR, W_SLOTS - 1);
       int ln = i & 63;
       int r = i >> 6;
       int tt = r % NT, ss = r / NT;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     }
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it) {
-      int i = threadIdx.x + it * 256;
+      int i = threadIdx.x + it * NTHR;
       if (i < W_SLOTS) w_s[i] = rw[it];
     }
   };
@@ -203,7 +213,16 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
   constexpr bool PREFETCH = (NT == 1);
   f32x4 acc[MT][NT];
   if (PREFETCH && total_stages > 0) prefetch(0);
+#ifdef MC_EXP_STAMPS   /* timing experiment only */
+  long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define STAMP(k) do { long long now_ = clock64(); st_acc[k] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
   for (int t = 0; t < total_stages; ++t) {
+#ifdef MC_EXP_STAMPS
+    long long st_prev = clock64();
+#endif
     const int jitem = t / chunks, ck = t - jitem * chunks;
     if (ck == 0) {
 #pragma unroll
@@ -212,12 +231,16 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
         for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){bv[tt][0], bv[tt][1], bv[tt][2], bv[tt][3]};   // bias folded in
     }
     if (!PREFETCH) prefetch(t);
-    __syncthreads();                                            // LDS free: previous MFMA loop done
+    MC_SYNC();                                            // LDS free: previous MFMA loop done
+    STAMP(0);
     commit();
     if (!WGLOBAL && (chunks > 1 || t == 0)) stage_weights(ck);
     const uint4* wglob = reinterpret_cast<const uint4*>(bank) + ((size_t)ck * STEPS * ntiles_total + ntile0) * 64 + lane;
-    __syncthreads();
+    STAMP(1);
+    MC_SYNC();
+    STAMP(2);
     if (PREFETCH && t + 1 < total_stages) prefetch(t + 1);      // in flight during the MFMA loop
+    STAMP(3);
     // ---- MFMA loop (rolled over the K-steps: the per-lane operand offset is recomputed per step)
     const int wbase = (wave * MT / MTILES_X) * TIW + ((wave * MT) % MTILES_X) * 16 + m;
     // K loop, software pipelined: the fragments of step s+1 are read from LDS (MT + NT ds_read_b128 into their own
@@ -250,12 +273,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
         for (int tt = 0; tt < NT; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt], xf[i], acc[i][tt], 0, 0, 0);
     };
 #ifndef MC_KPIPE
-#define MC_KPIPE 0   /* A/B on MI355X: ping-pong fragment registers gave no gain (the level-0 layers sit at ~2.5 TB/s algorithmic) */
+#define MC_KPIPE 0
 #endif
-#if MC_KPIPE
-#error "MC_KPIPE is selected per configuration below"
-#endif
-    if constexpr (WGLOBAL) {
+    if constexpr (WGLOBAL || MC_KPIPE == 2) {
     bf16x8 xa[MT], xb[MT], wa[NT], wb[NT];
     load_frags(0, xa, wa);
 #pragma unroll 1
@@ -268,11 +288,24 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
     } else {
     bf16x8 xa[MT], wa[NT];
 #pragma unroll 1
+#ifdef MC_EXP_NOK   /* timing experiment only */
+    for (int s = 0; s < 1; ++s) {
+#else
     for (int s = 0; s < STEPS; ++s) {
+#endif
       load_frags(s, xa, wa);
+#if MC_KPIPE == 1
+      // all fragment reads of the step first, each into its own registers, then the MFMAs: an MFMA waits only for ITS
+      // fragment (the default schedule reused one register quad and exposed the LDS latency before every MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+#endif
       do_mfma(xa, wa);
+#if MC_KPIPE == 1
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+#endif
     }
     }
+    STAMP(4);
     if (ck != chunks - 1) continue;
 
     // ---- epilogue of this work item, straight from the accumulators
@@ -316,7 +349,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
             s1[tt][0] += v01; s1[tt][1] += v23;
             s2[tt][0] = pk_fma(v01, v01, s2[tt][0]); s2[tt][1] = pk_fma(v23, v23, s2[tt][1]);
           }
+#ifdef MC_EXP_NOSTORE   /* timing experiment only */
+          if (inb && cobok[tt] && v01.x == 123.456f) {
+#else
           if (inb && cobok[tt]) {
+#endif
             if (OUT_F32) {
               *reinterpret_cast<float4*>(dst0[tt] + off) = make_float4(v01.x, v01.y, v23.x, v23.y);
             } else {
@@ -330,6 +367,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
       }
     };
     if (ty0 + TH <= g.Ho && tx0 + TW <= g.Wo) emit(std::true_type{}); else emit(std::false_type{});
+    STAMP(5);
     if (part) {
       // sum over the 16 pixel lanes of each 16-lane group with a halving butterfly (8 shuffles for the 8 values of an
       // N-tile instead of 32): afterwards lane m of a group holds the group total of value index m >> 1 (m even)
@@ -347,16 +385,23 @@ __global__ __launch_bounds__(256, (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_con
         // value index = 4 b3 + 2 b2 + b1 = (channel r = idx >> 1, idx & 1 = sum / sum of squares)
         if ((m & 1) == 0) red[wave][(tt * 16 + gq * 4) * 2 + (m >> 1)] = q1;
       }
-      __syncthreads();
+      MC_SYNC();
       if (threadIdx.x < NT * 32) {
         int co = ntile0 * 16 + (threadIdx.x >> 1);
         if (co < g.CoutP) {
-          float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+          float r = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < WAVES; ++wv) r += red[wv][threadIdx.x];
           part[(((size_t)n * g.tiles + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
         }
       }
     }
+    STAMP(6);
   }
+#ifdef MC_EXP_STAMPS
+  if (blockIdx.x == 777 && blockIdx.y == 0 && threadIdx.x == 0)
+    printf("stamps tiles %d: wait1 %lld commit %lld wait2 %lld pfetch %lld kloop %lld epi %lld stats %lld\n", my_items, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,10 +604,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   }
 }
 
+#ifndef MC_NT1_MT
+#define MC_NT1_MT 8     /* M-tiles per wave of the single-N-tile configuration: 8 -> 4 waves, 4 -> 8 waves per workgroup */
+#endif
 inline Bf16Cfg cfg_for(int c_out) {
   int ntiles = (c_out + 15) / 16;
   int nt = pick_nt(ntiles);
-  if (nt == 1) return {16, 32, 1, 8};
+  if (nt == 1) return {16, 32, 1, MC_NT1_MT};
   if (nt == 2) return {16, 16, 2, 4};
   return {16, 16, 4, 4};
 }
@@ -620,15 +668,15 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
   int bx = items < cap ? items : cap;
   dim3 grid(bx, groups, 1);
 #define LAUNCH(K, TH, TW, NT, MT)                                                                                    \
-  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT>), grid, dim3(256), 0, s, g, (const bf16_t*)x0,             \
+  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT>), grid, dim3(64 * (TH * (TW / 16) / MT)), 0, s, g, (const bf16_t*)x0, \
                      (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups)
   if (g.out_f32) {
-    if (g.K == 5) hipLaunchKernelGGL((k_conv_mfma_bf16<5, 16, 32, 1, 8, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
-    else hipLaunchKernelGGL((k_conv_mfma_bf16<3, 16, 32, 1, 8, true>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
+    if (g.K == 5) hipLaunchKernelGGL((k_conv_mfma_bf16<5, 16, 32, 1, MC_NT1_MT, true>), grid, dim3(64 * 32 / MC_NT1_MT), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
+    else hipLaunchKernelGGL((k_conv_mfma_bf16<3, 16, 32, 1, MC_NT1_MT, true>), grid, dim3(64 * 32 / MC_NT1_MT), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
   } else if (g.K == 5) {
-    if (c.nt == 1) LAUNCH(5, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4); else LAUNCH(5, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT); else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4); else LAUNCH(5, 16, 16, 4, 4);
   } else if (g.K == 3) {
-    if (c.nt == 1) LAUNCH(3, 16, 32, 1, 8); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4); else LAUNCH(3, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4); else LAUNCH(3, 16, 16, 4, 4);
   } else {
     return MC_EUNSUPPORTED;
   }
