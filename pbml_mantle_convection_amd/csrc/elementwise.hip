@@ -101,24 +101,51 @@ __global__ void k_sum_hw(const float* __restrict__ x, int hw, float scale, float
 // =================================================================================================
 // GroupNorm statistics from the conv epilogue's per-tile (sum, sumsq) partials
 // =================================================================================================
-// one block per (n, g); also optional per-(n,c) means (block g handles its own channels)
+// Per-channel totals of a [count][CP][2] partial array for the cpg channels of one group, one wave per (n, group).
+// Lane l owns channel l % cpg and every (64 / cpg)-th partial; the lanes of a channel are then combined with a butterfly
+// over the upper lane bits, so all channels of the group are summed at once (the former per-channel loop with two full
+// double-precision wave reductions per channel made these tiny kernels ~15 us each, 50 launches per step).
+// Requires cpg to be a power of two <= 64; afterwards EVERY lane holds the totals of its channel l % cpg.
+__device__ __forceinline__ void group_channel_sums(const float* __restrict__ part, size_t base_n, int count, int CP, int c0,
+                                                   int cpg, double& a1, double& a2) {
+  const int lane = threadIdx.x & 63, cl = lane % cpg, per = 64 / cpg;
+  a1 = 0.0; a2 = 0.0;
+  for (int t = lane / cpg; t < count; t += per) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((base_n + t) * CP + c0 + cl) * 2);
+    a1 += (double)v.x;
+    a2 += (double)v.y;
+  }
+  for (int o = cpg; o < 64; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+}
+__device__ __forceinline__ bool pow2_le64(int v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; }
+
+// one wave per (n, g); also optional per-(n,c) means (block g handles its own channels)
 __global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, int CP, int groups, int hw,
                               float eps, float* __restrict__ stats, float* __restrict__ chan_mean) {
   const int n = blockIdx.y, g = blockIdx.x;
   const int cpg = C / groups;
   double s = 0.0, ss = 0.0;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    double cs = 0.0, css = 0.0;
-    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
-      const float* p = part + (((size_t)n * tiles + t) * CP + c) * 2;
-      cs += (double)p[0];
-      css += (double)p[1];
+  if (pow2_le64(cpg)) {
+    double cs, css;
+    group_channel_sums(part, (size_t)n * tiles, tiles, CP, g * cpg, cpg, cs, css);
+    const int lane = threadIdx.x & 63;
+    if (chan_mean && lane < cpg) chan_mean[n * C + g * cpg + lane] = (float)(cs / (double)hw);
+    s = cs; ss = css;
+    for (int o = 1; o < cpg; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  } else {
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      double cs = 0.0, css = 0.0;
+      for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+        const float* p = part + (((size_t)n * tiles + t) * CP + c) * 2;
+        cs += (double)p[0];
+        css += (double)p[1];
+      }
+      cs = wave_sum_d(cs);
+      css = wave_sum_d(css);
+      if (chan_mean && threadIdx.x == 0) chan_mean[n * C + c] = (float)(cs / (double)hw);
+      s += cs;
+      ss += css;
     }
-    cs = wave_sum_d(cs);
-    css = wave_sum_d(css);
-    if (chan_mean && threadIdx.x == 0) chan_mean[n * C + c] = (float)(cs / (double)hw);
-    s += cs;
-    ss += css;
   }
   if (threadIdx.x == 0 && stats) {
     double m = (double)cpg * (double)hw;
@@ -134,6 +161,12 @@ __global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, 
 // a = act(GN(y)) [+ AvgPool(POOL)(a)]
 // =================================================================================================
 constexpr int GN_ROWS = 8;
+// launch-shape knobs (environment overrides are for tuning runs only)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int gn_fwd_vpt() { static int v = env_int("MC_GN_FWD_VPT", 8); return v; }
+// rows per block of the backward-apply kernel (tools/bench_gn.py sweep on MI355X): 8 rows for wide images, more for narrow
+// ones so that a block still streams >= 16 vectors per thread
+static int gn_apply_rows(int h, int w) { static int v = env_int("MC_GN_ROWS", 0); if (v > 0) return v; return w > 256 ? GN_ROWS : (w > 32 ? 16 : 32); }
 
 struct GnArgs {
   int N, C, C8, H, W, groups, cpg, post, act;
@@ -276,6 +309,18 @@ __global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blo
                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int g = blockIdx.x, n = blockIdx.y, cpg = C / groups;
   double m1 = 0.0, m2 = 0.0;
+  if (pow2_le64(cpg)) {
+    double a1, a2;
+    group_channel_sums(part, (size_t)n * blocks, blocks, CP, g * cpg, cpg, a1, a2);
+    const int lane = threadIdx.x & 63, c = g * cpg + (lane % cpg);
+    if (lane < cpg) {
+      if (dgamma) atomicAdd(dgamma + c, (float)a2);
+      if (dbeta) atomicAdd(dbeta + c, (float)a1);
+    }
+    const float ga = gamma ? gamma[c] : 1.f;
+    m1 = ga * a1; m2 = ga * a2;
+    for (int o = 1; o < cpg; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+  } else {
   for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
     double a1 = 0.0, a2 = 0.0;
     for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
@@ -293,6 +338,7 @@ __global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blo
       if (dbeta) atomicAdd(dbeta + c, (float)a1);
     }
   }
+  }
   if (threadIdx.x == 0 && m12) {
     double M = (double)cpg * (double)hw;
     m12[((size_t)n * groups + g) * 2 + 0] = (float)(m1 / M);
@@ -305,7 +351,7 @@ template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restrict__ y, const float* __restrict__ m12,
                                                       mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy,
                                                       const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta) {
+                                                      float* __restrict__ dbeta, int rows_pb) {
   const int n = blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8], mean[8], rstd[8], ga[8], m1[8], m2[8];
   gn_coef(a, n, cb, sc, sh);
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
   // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over several
   // vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s).  (A 4-way manual batching
   // of the loads was tried and was SLOWER: 131 VGPRs cut the occupancy of this streaming kernel.)
-  const int y0 = blockIdx.x * GN_ROWS, nrows = min(GN_ROWS, a.H - y0);
+  const int y0 = blockIdx.x * rows_pb, nrows = min(rows_pb, a.H - y0);
   for (int i = threadIdx.x; i < nrows * a.W; i += blockDim.x) {      // rows x columns flattened (narrow images)
     const int ry = i / a.W, xx = i - ry * a.W, yy = y0 + ry;
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
@@ -874,7 +920,7 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   if (pool != 1 && pool != 2 && pool != 4) return MC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int per = cdiv(h, pool) * cdiv(w, pool);
-  dim3 g(max(1, min(cdiv(per, 256 * 8), 4096)), a.C8, n);
+  dim3 g(max(1, min(cdiv(per, 256 * gn_fwd_vpt()), 4096)), a.C8, n);
 #define GN_LAUNCH(T, P) hipLaunchKernelGGL((k_gn_act_fwd<T, P>), g, dim3(256), 0, s, a, (const T*)y, (T*)a_out, (T*)pooled)
   if (dtype == MC_F32) { if (pool == 1) GN_LAUNCH(float, 1); else if (pool == 2) GN_LAUNCH(float, 2); else GN_LAUNCH(float, 4); }
   else if (dtype == MC_BF16) { if (pool == 1) GN_LAUNCH(bf16_t, 1); else if (pool == 2) GN_LAUNCH(bf16_t, 2); else GN_LAUNCH(bf16_t, 4); }
@@ -898,7 +944,11 @@ int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, in
 }
 
 int32_t mc_gn_bwd_blocks(int32_t h, int32_t w) {
-  int b = cdiv(h * w, 256 * 8);
+  static int env_vpt = env_int("MC_GN_RED_VPT", 0);
+  // vectors per thread of the phase-1 reduction: 32 on large images (fewer, longer blocks amortise the 16-value block
+  // reduction: 161 -> 140 us at 506 x 512), 8 otherwise (tools/bench_gn.py sweep)
+  const int vpt = env_vpt > 0 ? env_vpt : ((long)h * w >= 200000 ? 32 : 8);
+  int b = cdiv(h * w, 256 * vpt);
   if (b > 128) b = 128;
   if (b < 1) b = 1;
   return b;
@@ -953,10 +1003,11 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   if (!y || !dy || !g0 || (post == MC_POST_GN_ACT && !m12)) return MC_EINVAL;
   if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
   if (post == MC_POST_NONE) a.act = MC_ACT_NONE;
-  dim3 g(cdiv(h, GN_ROWS), a.C8, n);
+  const int rows = gn_apply_rows(h, w);
+  dim3 g(cdiv(h, rows), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, false>), g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, nullptr, 0, nullptr, nullptr);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, false>), g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, nullptr, 0, nullptr, nullptr);
+  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, false>), g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, nullptr, 0, nullptr, nullptr, rows);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, false>), g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, nullptr, 0, nullptr, nullptr, rows);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -988,10 +1039,11 @@ int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, in
   if (!y || !dy || !g0 || !partials || blocks <= 0) return MC_EINVAL;
   if (a.cpg > 8 || (8 % a.cpg) != 0) return MC_EUNSUPPORTED;   // a group must not straddle 8-channel blocks
   if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
-  dim3 g(cdiv(h, GN_ROWS), a.C8, n);
+  const int rows = gn_apply_rows(h, w);
+  dim3 g(cdiv(h, rows), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, true>), g, dim3(256), 0, s, a, (const float*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, partials, blocks, dgamma, dbeta);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, true>), g, dim3(256), 0, s, a, (const bf16_t*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, partials, blocks, dgamma, dbeta);
+  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, true>), g, dim3(256), 0, s, a, (const float*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, partials, blocks, dgamma, dbeta, rows);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, true>), g, dim3(256), 0, s, a, (const bf16_t*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, partials, blocks, dgamma, dbeta, rows);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;

@@ -3,7 +3,7 @@
 reps=$1; shift
 for r in $(seq $reps); do
   for kv in "$@"; do
-    ms=$(env $kv python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; print("%.3f" % json.loads(sys.stdin.read())["ms_per_step"])')
+    ms=$(env $kv python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; print("%.3f" % json.loads(sys.stdin.read())["ms_per_step"])')
     echo "$kv $ms"
   done
 done
