@@ -210,7 +210,10 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 
   // cross-stage register prefetch only where the register budget allows it (single N-tile configuration);
   // the wider configurations load and commit a stage back to back (their K loop is MT*NT MFMAs per fragment pair)
-  constexpr bool PREFETCH = (NT == 1);
+#ifndef MC_PREFETCH_ALL
+#define MC_PREFETCH_ALL 0
+#endif
+  constexpr bool PREFETCH = (NT == 1) || MC_PREFETCH_ALL;
   f32x4 acc[MT][NT];
   if (PREFETCH && total_stages > 0) prefetch(0);
 #ifdef MC_EXP_STAMPS   /* timing experiment only */

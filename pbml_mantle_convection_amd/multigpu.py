@@ -235,10 +235,10 @@ class Trainer:
                 with torch.cuda.graph(self._graph_opt):
                     self._optim_step()
         st = self._static
-        st["gVTp"].copy_(gVTp, non_blocking=True)
-        st["uvp"].copy_(uvp, non_blocking=True)
-        for k, v in (("yc", yc), ("paras", paras), ("scaler", scaler)):
-            if st[k] is not None and v is not None:
+        # a captured step reads its inputs from fixed buffers; a caller that fills `input_buffers()` in place (a loader
+        # writing the next batch straight into them) passes those very tensors and no copy is made
+        for k, v in (("gVTp", gVTp), ("uvp", uvp), ("yc", yc), ("paras", paras), ("scaler", scaler)):
+            if st[k] is not None and v is not None and v.data_ptr() != st[k].data_ptr():
                 st[k].copy_(v.reshape(st[k].shape), non_blocking=True)
         self._graph.replay()
         if self.world == 1:
@@ -247,6 +247,14 @@ class Trainer:
             allreduce_flat(self.flat.grad)
             self._optim_step()
         return self._static_out
+
+    def input_buffers(self):
+        """The device tensors a captured training step reads (available after the first `train_step` with
+        use_graph): dict(gVTp, uvp, yc, paras, scaler).  Writing a batch into them and passing them to `train_step`
+        skips the device-to-device staging copy."""
+        if self._graph is None:
+            raise RuntimeError("input_buffers() is available after the first graph-captured train_step")
+        return dict(self._static)
 
     def eval_step(self, gVTp, uvp, yc=None, paras=None, scaler=None):
         return self._fwd_bwd(gVTp, uvp, yc, paras, scaler, train=False)

@@ -194,3 +194,34 @@ def test_get_loss_autograd_path(golden):
     for n, p in m.named_parameters():
         ref = g["grad0/" + n]
         close(p.grad, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
+
+
+def test_graph_step_in_place_input_buffers():
+    """A batch written straight into the captured step's input buffers gives the same step as one passed by value."""
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    res = []
+    for in_place in (False, True):
+        torch.manual_seed(3)
+        m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+        tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet",
+                     loss_type="mass", lambda_mom=0.1, precision="fp32", use_graph=True)
+        b0 = [t.to(DEV) for t in synthetic_batch(2, 48, 70, 11, p_pred=True, device="cpu")]
+        b1 = [t.to(DEV) for t in synthetic_batch(2, 48, 70, 12, p_pred=True, device="cpu")]
+        with pytest.raises(RuntimeError):
+            tr.input_buffers()
+        order = lambda b: (b[0], b[1], b[4], b[3], b[2])          # (gVTp, uvp, scaler, paras, yc) -> train_step order
+        tr.train_step(*order(b0))
+        if in_place:
+            buf = tr.input_buffers()
+            for k, v in zip(("gVTp", "uvp", "yc", "paras", "scaler"), order(b1)):
+                buf[k].copy_(v.reshape(buf[k].shape))
+            out = tr.train_step(buf["gVTp"], buf["uvp"], buf["yc"], buf["paras"], buf["scaler"])
+        else:
+            out = tr.train_step(*order(b1))
+        res.append((out.clone(), torch.cat([p.detach().flatten() for p in m.parameters()]).clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
