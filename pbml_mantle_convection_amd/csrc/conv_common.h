@@ -27,6 +27,11 @@ static __host__ __device__ inline size_t wg_slab_floats(int CoutP, int CinP, int
 static __host__ __device__ inline size_t wg_index(int tap, int cip, int co, int CoutP, int nch) {
   return ((size_t)(tap * nch + (cip >> 4)) * CoutP + co) * 16 + (cip & 15);
 }
+static inline long wgrad_target_blocks2() {
+  static long v = 0;
+  if (!v) { const char* e = getenv("MC_WGRAD_BLOCKS2"); v = e ? atol(e) : 512; if (v < 16) v = 16; }
+  return v;
+}
 static inline long wgrad_target_blocks() {
   static long v = 0;
   if (!v) { const char* e = getenv("MC_WGRAD_BLOCKS"); v = e ? atol(e) : 768; if (v < 16) v = 16; }
@@ -70,7 +75,10 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
     int ntiles = (g.Cout + 15) / 16;
     int ntw = (ntiles % 2 == 0) ? 2 : 1;
     long other = (long)((g.CBin + 1) / 2) * ((ntiles + ntw - 1) / ntw);
-    G = (wgrad_target_blocks() + other - 1) / other;
+    // resident workgroups: 3 per CU with one co-tile per block (39 KB LDS), 2 per CU with two (55 KB); a grid of exactly
+    // one resident wave avoids a half-empty second wave
+    const long target = ntw == 1 ? wgrad_target_blocks() : wgrad_target_blocks2();
+    G = (target + other - 1) / other;
     if (G < 16) G = 16;
     work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
   } else {
