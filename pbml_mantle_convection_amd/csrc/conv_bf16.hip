@@ -259,7 +259,11 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         if (WGLOBAL) {
+#ifdef MC_EXP_NOWLOAD   /* timing experiment only: wrong results */
+          uint4 wv = make_uint4(sidx, tt, lane, 0);
+#else
           uint4 wv = wglob[((size_t)sidx * ntiles_total + tt) * 64];
+#endif
           wf[tt] = __builtin_bit_cast(bf16x8, wv);
         } else {
           wf[tt] = *reinterpret_cast<const bf16x8*>(&w_s[(sidx * NT + tt) * 64 + lane]);

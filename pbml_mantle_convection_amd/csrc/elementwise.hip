@@ -414,6 +414,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
       } else { ga[j] = 1.f; rstd[j] = 1.f; }
     }
   }
+  float cA[8], cB[8], cC[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cA[j] = rstd[j] * ga[j];                          // (act-only layers: rstd = ga = 1, m1 = m2 = 0)
+    cB[j] = -rstd[j] * rstd[j] * m2[j];
+    cC[j] = -rstd[j] * m1[j];
+  }
   // each block streams GN_ROWS rows: the per-(n, channel-block) coefficient prologue is amortised over several
   // vectors per thread (one vector per thread left these kernels latency-bound at ~1.3 TB/s).  (A 4-way manual batching
   // of the loads was tried and was SLOWER: 131 VGPRs cut the occupancy of this streaming kernel.)
@@ -427,15 +434,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
     grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
     float gz[8];
     act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
+    // dy = rstd (gamma dz - m1 - yhat m2) = cA dz + cB (y - mean) + cC  (three packed FMAs per channel pair)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float dz = da[j] * gz[j];
-      if (a.post == MC_POST_GN_ACT) {
-        float yh = (v[j] - mean[j]) * rstd[j];
-        o[j] = rstd[j] * (dz * ga[j] - m1[j] - yh * m2[j]);
-      } else {
-        o[j] = dz * ga[j];
-      }
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 dz = (f32x2){da[j], da[j + 1]} * (f32x2){gz[j], gz[j + 1]};
+      const f32x2 t = (f32x2){v[j], v[j + 1]} - (f32x2){mean[j], mean[j + 1]};
+      const f32x2 r = pk_fma((f32x2){cA[j], cA[j + 1]}, dz, pk_fma((f32x2){cB[j], cB[j + 1]}, t, (f32x2){cC[j], cC[j + 1]}));
+      o[j] = r.x; o[j + 1] = r.y;
     }
     V8<T>::st(dy + idx, o);
   }
