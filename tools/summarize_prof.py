@@ -14,7 +14,8 @@ with open(dst, "w") as o:
     o.write(f"# rocprofv3 --kernel-trace --stats summary\n\nsource: `{f.split('gpurun_out/')[-1]}`; passes in run: {steps:g} "
             f"(warm-up + timed + instrumented); total kernel time {tot / 1e6:.2f} ms = {tot / 1e6 / steps:.2f} ms per pass\n\n")
     if len(sys.argv) > 4:
-        o.write("bench line of the same run:\n\n```\n" + open(sys.argv[4]).read().strip().splitlines()[-1] + "\n```\n\n")
+        lines = [l for l in open(sys.argv[4]).read().splitlines() if l.startswith("{")]
+        o.write("bench line of the same run:\n\n```\n" + (lines[-1] if lines else "(no JSON line found)") + "\n```\n\n")
     o.write("| kernel | calls | avg µs | min µs | max µs | ms per pass | % |\n|---|---|---|---|---|---|---|\n")
     for r in rows:
         if float(r["TotalDurationNs"]) / tot < 5e-4:
