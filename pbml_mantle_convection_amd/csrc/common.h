@@ -255,14 +255,17 @@ __device__ __forceinline__ int fold_candidates(int i, int n, int p, int mode, in
   return cnt;
 }
 
-template <typename T>
+// KIND >= 0 fixes the source kind at compile time (the GroupNorm-backward kernels are instantiated for the common
+// (source 0, source 1) pairs: their streaming loops are register- and SGPR-bound, and the generic dispatch costs both)
+template <typename T, int KIND = -1>
 __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int cb, int y, int x, int C8,
                                                float (&acc)[8]) {
   // PADDED sources have had the padding adjoint folded onto their interior by mc_fold_padded: read at offset pad.
-  if (g.kind == MC_GSRC_NONE || g.ptr == nullptr) return;
+  const int kind = KIND >= 0 ? KIND : g.kind;
+  if (kind == MC_GSRC_NONE || (KIND < 0 && g.ptr == nullptr)) return;
   const T* base = reinterpret_cast<const T*>(g.ptr);
   float v[8];
-  if (g.kind == MC_GSRC_PLAIN) {
+  if (kind == MC_GSRC_PLAIN) {
     V8<T>::ld(base + cb8_index(n, cb, y, x, C8, g.hs, g.ws), v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] += v[j];
@@ -270,7 +273,7 @@ __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int 
   }
   float scale = 1.0f;
   int yy = y, xx = x;
-  if (g.kind == MC_GSRC_PADFOLD_POOL) {
+  if (kind == MC_GSRC_PADFOLD_POOL) {
     if (g.pool == 2) { yy = y >> 1; xx = x >> 1; } else { yy = y / g.pool; xx = x / g.pool; }
     if (yy >= g.hs || xx >= g.ws) return;   // floor mode: trailing rows/cols are not pooled
     scale = 1.0f / (float)(g.pool * g.pool);

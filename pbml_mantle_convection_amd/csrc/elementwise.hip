@@ -251,7 +251,20 @@ __global__ void k_avgpool(const T* __restrict__ x, int C8, int H, int W, int f, 
 // backward of act(GN(y))
 // =================================================================================================
 // phase 1: partial[n][blk][c][2] = (sum dz, sum dz * yhat) over this block's pixels
-template <typename T>
+// GK: compile-time (source 0, source 1) kinds: 0 = decided at run time, 1 = (PADFOLD, NONE), 2 = (PLAIN, NONE),
+// 3 = (PADFOLD, PADFOLD_POOL)
+template <int GK> struct GKinds {
+  static constexpr int k0 = GK == 1 ? MC_GSRC_PADFOLD : (GK == 2 ? MC_GSRC_PLAIN : (GK == 3 ? MC_GSRC_PADFOLD : -1));
+  static constexpr int k1 = (GK == 1 || GK == 2) ? MC_GSRC_NONE : (GK == 3 ? MC_GSRC_PADFOLD_POOL : -1);
+};
+static int gkind_of(const mc_grad_src& g0, const mc_grad_src& g1) {
+  if (g0.kind == MC_GSRC_PADFOLD && g1.kind == MC_GSRC_NONE) return 1;
+  if (g0.kind == MC_GSRC_PLAIN && g1.kind == MC_GSRC_NONE) return 2;
+  if (g0.kind == MC_GSRC_PADFOLD && g1.kind == MC_GSRC_PADFOLD_POOL) return 3;
+  return 0;
+}
+
+template <typename T, int GK>
 __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
                                                        mc_grad_src g1, float* __restrict__ part, int CP) {
   const int n = blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
@@ -274,8 +287,8 @@ __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __r
     const int ry = i / a.W, xx = i - ry * a.W, yy = blk + ry * nblk;
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
-    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
-    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
     float ga[8];
     act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, ga);
 #pragma unroll
@@ -347,7 +360,7 @@ __global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blo
 }
 
 // phase 3: dy = rstd (dz gamma - m1 - yhat m2)   (GN)   |   dy = da act'(y)   (act only)
-template <typename T, bool FUSED>
+template <typename T, bool FUSED, int GK = 0>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restrict__ y, const float* __restrict__ m12,
                                                       mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy,
                                                       const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
@@ -430,8 +443,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
     size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
     V8<T>::ld(y + idx, v);
-    grad_fetch_add<T>(g0, n, cb, yy, xx, a.C8, da);
-    grad_fetch_add<T>(g1, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
     float gz[8];
     act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
     // dy = rstd (gamma dz - m1 - yhat m2) = cA dz + cB (y - mean) + cC  (three packed FMAs per channel pair)
@@ -983,9 +996,13 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
   if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
   dim3 g(mc_gn_bwd_blocks(h, w), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_bwd_reduce<float>, g, dim3(256), 0, s, a, (const float*)y, gsrc_or_none(g0), gsrc_or_none(g1), partials, a.C8 * 8);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_bwd_reduce<bf16_t>, g, dim3(256), 0, s, a, (const bf16_t*)y, gsrc_or_none(g0), gsrc_or_none(g1), partials, a.C8 * 8);
-  else return MC_EUNSUPPORTED;
+  const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
+#define RED(T, GK) hipLaunchKernelGGL((k_gn_bwd_reduce<T, GK>), g, dim3(256), 0, s, a, (const T*)y, s0, s1, partials, a.C8 * 8)
+  if (dtype == MC_F32) RED(float, 0);
+  else if (dtype == MC_BF16) {
+    switch (gkind_of(s0, s1)) { case 1: RED(bf16_t, 1); break; case 2: RED(bf16_t, 2); break; case 3: RED(bf16_t, 3); break; default: RED(bf16_t, 0); }
+  } else return MC_EUNSUPPORTED;
+#undef RED
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -1011,9 +1028,13 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   const int rows = gn_apply_rows(h, w);
   dim3 g(cdiv(h, rows), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, false>), g, dim3(256), 0, s, a, (const float*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, nullptr, 0, nullptr, nullptr, rows);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, false>), g, dim3(256), 0, s, a, (const bf16_t*)y, m12, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, nullptr, 0, nullptr, nullptr, rows);
-  else return MC_EUNSUPPORTED;
+  const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
+#define APP(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply<T, false, GK>), g, dim3(256), 0, s, a, (const T*)y, m12, s0, s1, (T*)dy, nullptr, 0, nullptr, nullptr, rows)
+  if (dtype == MC_F32) APP(float, 0);
+  else if (dtype == MC_BF16) {
+    switch (gkind_of(s0, s1)) { case 1: APP(bf16_t, 1); break; case 2: APP(bf16_t, 2); break; case 3: APP(bf16_t, 3); break; default: APP(bf16_t, 0); }
+  } else return MC_EUNSUPPORTED;
+#undef APP
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
