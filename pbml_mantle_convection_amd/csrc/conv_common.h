@@ -78,7 +78,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
     // resident workgroups: 3 per CU with one co-tile per block (39 KB LDS), 2 per CU with two (55 KB); a grid of exactly
     // one resident wave avoids a half-empty second wave
     const long target = ntw == 1 ? wgrad_target_blocks() : wgrad_target_blocks2();
-    G = (target + other - 1) / other;
+    G = ntw == 1 ? (target + other - 1) / other : target / other;      // two co-tiles: never spill into a second resident wave
     if (G < 16) G = 16;
     work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
   } else {
