@@ -283,19 +283,35 @@ __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __r
   // rows blk, blk + nblk, ... of this block, flattened with the columns so that narrow images (W < 256) still use every
   // thread (a per-row loop left 7/8 of the threads idle at the deep levels: ~25 us floor per launch)
   const int nrows = (a.H - blk + nblk - 1) / nblk;
-  for (int i = threadIdx.x; i < nrows * a.W; i += blockDim.x) {
-    const int ry = i / a.W, xx = i - ry * a.W, yy = blk + ry * nblk;
-    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
-    grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
-    grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
-    float ga[8];
-    act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, ga);
+#ifndef MC_GN_RED_UNROLL
+#define MC_GN_RED_UNROLL 1   /* A/B on MI355X: 2 = no gain (4.1 TB/s either way), 4 spills (3x slower) */
+#endif
+  // MC_GN_RED_UNROLL positions per iteration, every load issued before the first use: the loop is bound by the bytes it
+  // keeps in flight (two 16-byte loads per position), not by arithmetic
+  const int total = nrows * a.W;
+  for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * MC_GN_RED_UNROLL) {
+    float v[MC_GN_RED_UNROLL][8], da[MC_GN_RED_UNROLL][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float dz = da[j] * ga[j];
-      s1[j] += dz;
-      s2[j] += dz * (v[j] - mean[j]) * rstd[j];
+    for (int u = 0; u < MC_GN_RED_UNROLL; ++u) {
+      const int i = min(i0 + u * (int)blockDim.x, total - 1);
+      const int ry = i / a.W, xx = i - ry * a.W, yy = blk + ry * nblk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) da[u][j] = 0.f;
+      V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v[u]);
+      grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da[u]);
+      grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < MC_GN_RED_UNROLL; ++u) {
+      const float live = (i0 + u * (int)blockDim.x < total) ? 1.f : 0.f;     // the clamped tail position contributes nothing
+      float ga[8];
+      act_bwd8<FastMath<T>::value>(v[u], sc, sh, a.act, ga);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float dz = live * da[u][j] * ga[j];
+        s1[j] += dz;
+        s2[j] += dz * (v[u][j] - mean[j]) * rstd[j];
+      }
     }
   }
   __shared__ float red[4][16];
