@@ -268,6 +268,7 @@ class Engine:
         self.fused_gn_bwd = os.environ.get("MANTLE_FUSED_GN_BWD", "0") != "0"   # A/B on MI355X: the fused form is 0.45 ms/step slower (131 VGPRs)
         # filter-gradient kernels on a second stream: 0 = never, 1 = every layer, 2 = only layers of <= 128 x 128 pixels
         # (their launches are latency-bound and leave most of the chip idle)
+        self.wfin_per_layer = os.environ.get("MANTLE_WFIN_PER_LAYER", "1") != "0"   # A/B on MI355X: -0.14 ms/step (the combine leaves the tail of the step)
         self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "1"))   # A/B on MI355X: 1 is 0.25 ms/step faster than 0, 2 is no gain
 
     # -------------------------------------------------------------- planning
@@ -394,9 +395,18 @@ class Engine:
         st = L.stream()
         g, T = self.g, self.T
         act = L.ACTS[g.act]
+        if self.overlap_wgrad:
+            # filter banks are packed on the side stream while the input is converted on the main one
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._pack_all_banks(params, L.stream())
         L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
                L.ptr(T[0].buf), st)
-        self._pack_all_banks(params, st)
+        if self.overlap_wgrad:
+            main.wait_stream(self.side)
+        else:
+            self._pack_all_banks(params, st)
         for e in self.plan:
             node = e["node"]
             if node.kind == "up":
@@ -529,6 +539,13 @@ class Engine:
             with torch.cuda.stream(side):
                 ss = L.stream()
                 L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(e["wpart"]), ss)
+                if self.wfin_per_layer and side is not main:
+                    # combine this layer's partial slabs right away on the side stream (hidden under the main chain)
+                    L.call("mc_conv2d_wgrad_finalize", C.byref(d), L.ptr(e["wpart"]), L.ptr(grads[node.name + "weight"]),
+                           L.ptr(grads[node.name + "bias"]), ss)
+                    e["_wfin_done"] = True
+                else:
+                    e["_wfin_done"] = False
                 if side is not main:
                     wg_done[k & 1] = torch.cuda.Event()
                     wg_done[k & 1].record(side)
@@ -546,12 +563,14 @@ class Engine:
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(self.side)
         # one launch combines every layer's partial slabs, folds mirrored filters and accumulates into the gradients
-        n = len(self.convs)
-        descs = (L.ConvDesc * n)(*[e["desc"] for e in self.convs])
-        parts = (C.c_void_p * n)(*[L.ptr(e["wpart"]) for e in self.convs])
-        dws = (C.c_void_p * n)(*[L.ptr(grads[e["node"].name + "weight"]) for e in self.convs])
-        dbs = (C.c_void_p * n)(*[L.ptr(grads[e["node"].name + "bias"]) for e in self.convs])
-        L.call("mc_conv2d_wgrad_finalize_batched", descs, parts, dws, dbs, n, st)
+        todo = [e for e in self.convs if not e.get("_wfin_done")]
+        n = len(todo)
+        if n:
+            descs = (L.ConvDesc * n)(*[e["desc"] for e in todo])
+            parts = (C.c_void_p * n)(*[L.ptr(e["wpart"]) for e in todo])
+            dws = (C.c_void_p * n)(*[L.ptr(grads[e["node"].name + "weight"]) for e in todo])
+            dbs = (C.c_void_p * n)(*[L.ptr(grads[e["node"].name + "bias"]) for e in todo])
+            L.call("mc_conv2d_wgrad_finalize_batched", descs, parts, dws, dbs, n, st)
 
     def _pack_all_banks(self, params, st):
         """Forward and input-gradient banks of every layer in one batched launch per 24 jobs (weights are fixed
