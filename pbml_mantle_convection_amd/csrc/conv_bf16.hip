@@ -475,8 +475,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   const short* xtap[NTAP];                                      // this lane's x-tile address per tap (row 0)
 #pragma unroll
   for (int ti = 0; ti < NTAP; ++ti) xtap[ti] = xs_s + lane_x + max(toff[ti], 0);
-  // static staging slots of this thread
+  // static staging slots of this thread (decoded once: the staging address arithmetic was a third of the kernel's VALU work)
   int x_rc[X_ITERS];
+  unsigned x_off[X_ITERS];
+  int x_lds[X_ITERS];
 #pragma unroll
   for (int it = 0; it < X_ITERS; ++it) {
     int i = threadIdx.x + it * 256;
@@ -486,7 +488,22 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     int rem = i - cb * (TIH * TIW);
     int r = rem / TIW, c = rem - r * TIW;
     x_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;
+    x_off[it] = (unsigned)(r * g.W + c) * 16u;
+    x_lds[it] = live ? cb * XPS + r * TIW + c : -1;
   }
+  // dy staging: static element offset of this thread's slots inside a (image, co-group) tile that lies fully inside
+  unsigned d_off[D_ITERS];
+  int d_lds[D_ITERS];
+#pragma unroll
+  for (int it = 0; it < D_ITERS; ++it) {
+    int i = threadIdx.x + it * 256;
+    int pl = i / (WTH * WTW);
+    int rem = i - pl * (WTH * WTW);
+    int r = rem / WTW, c = rem - r * WTW;
+    d_off[it] = (unsigned)((pl * g.Ho + r) * g.Wo + c) * 16u;
+    d_lds[it] = pl * DPS + rem;
+  }
+  const bool co_full = (cog * NTW + NTW) * 2 <= g.CBout;        // every co plane of this block exists
   // channel blocks of this (chunk): uniform
   const char* xbase[2];
   bool xok[2];
@@ -507,22 +524,34 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     const int n = wi / tiles, tile = wi - n * tiles;
     const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
+    const char* bpn[2] = {xbase[0] + (size_t)n * xC8[0] * g.H * g.W * 16, xbase[1] + (size_t)n * xC8[1] * g.H * g.W * 16};
+    if (interior) {
+      const size_t org = (size_t)((ty0 - g.pad) * g.W + (tx0 - g.pad)) * 16;
 #pragma unroll
-    for (int it = 0; it < X_ITERS; ++it) {
-      int r = (x_rc[it] >> 15) & 0x7fff, c = x_rc[it] & 0x7fff;
-      bool cb1 = ((x_rc[it] >> 30) & 1) != 0;
-      const char* bp = (cb1 ? xbase[1] : xbase[0]) + (size_t)n * (cb1 ? xC8[1] : xC8[0]) * g.H * g.W * 16;
-      bool ok = cb1 ? xok[1] : xok[0];
-      int sy, sx;
-      if (interior) { sy = ty0 - g.pad + r; sx = tx0 - g.pad + c; }
-      else {
-        bool oky, okx;
-        sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
-        sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
-        ok = ok && oky && okx;
+      for (int it = 0; it < X_ITERS; ++it) {
+        const bool cb1 = ((x_rc[it] >> 30) & 1) != 0;
+        uint4 v = *reinterpret_cast<const uint4*>((cb1 ? bpn[1] : bpn[0]) + org + x_off[it]);
+        rx[it] = (cb1 ? xok[1] : xok[0]) ? v : make_uint4(0, 0, 0, 0);
       }
-      uint4 v = *reinterpret_cast<const uint4*>(bp + (size_t)(sy * g.W + sx) * 16);
-      rx[it] = ok ? v : make_uint4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < X_ITERS; ++it) {
+        int r = (x_rc[it] >> 15) & 0x7fff, c = x_rc[it] & 0x7fff;
+        bool cb1 = ((x_rc[it] >> 30) & 1) != 0;
+        bool ok = cb1 ? xok[1] : xok[0];
+        bool oky, okx;
+        int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
+        int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
+        ok = ok && oky && okx;
+        uint4 v = *reinterpret_cast<const uint4*>((cb1 ? bpn[1] : bpn[0]) + (size_t)(sy * g.W + sx) * 16);
+        rx[it] = ok ? v : make_uint4(0, 0, 0, 0);
+      }
+    }
+    if (co_full && ty0 + WTH <= g.Ho && tx0 + WTW <= g.Wo) {
+      const char* db = reinterpret_cast<const char*>(dy) + cb8_index(n, cog * NTW * 2, ty0, tx0, g.CBout, g.Ho, g.Wo) * sizeof(bf16_t);
+#pragma unroll
+      for (int it = 0; it < D_ITERS; ++it) rd[it] = *reinterpret_cast<const uint4*>(db + d_off[it]);
+      return;
     }
 #pragma unroll
     for (int it = 0; it < D_ITERS; ++it) {
@@ -541,16 +570,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < X_ITERS; ++it)
-      if (x_rc[it] >= 0) {
-        int r = (x_rc[it] >> 15) & 0x7fff, c = x_rc[it] & 0x7fff, cb = (x_rc[it] >> 30) & 1;
-        xs[cb * XPS + r * TIW + c] = rx[it];
-      }
+      if (x_lds[it] >= 0) xs[x_lds[it]] = rx[it];
 #pragma unroll
-    for (int it = 0; it < D_ITERS; ++it) {
-      int i = threadIdx.x + it * 256;
-      int pl = i / (WTH * WTW);
-      ds[pl * DPS + (i - pl * (WTH * WTW))] = rd[it];
-    }
+    for (int it = 0; it < D_ITERS; ++it) ds[d_lds[it]] = rd[it];
   };
 
   f32x4 acc[NTAP][NTW];
