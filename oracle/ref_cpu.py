@@ -320,6 +320,63 @@ def unet_forward(sd, x, *, levels, repeats, act="gelu", r_p="replicate", loss_ty
 
 
 # --------------------------------------------------------------------------------------
+# NewFluidNet (pytorch_networks_convae.py:1068-1390) — SURVEY.md §8(f) row N1
+# --------------------------------------------------------------------------------------
+def newfluidnet_layer_table(levels: int, c_i: int, c_h: int, c_o: int, repeats: int) -> list:
+    """(state-dict prefix, C_in, C_out, k or None (= f), kind) in ctor order (:1215-1313)."""
+    t = [("conv.0.", c_i, c_h, None, "fluid")]
+    for l in range(levels):
+        for r in range(repeats):
+            t.append((f"convs.{l}.{r}.", c_h, c_h, None, "fluid"))
+    t.append(("conv.1.", c_h * levels + c_i, c_h, 3, "head_gn"))
+    t.append(("conv.2.", c_h, c_h, 3, "head_act"))
+    t.append(("conv.3.", c_h, c_o, 3, "head_out"))
+    return t
+
+
+def newfluidnet_features(sd, x, *, levels, repeats, act, r_p, use_symm, factor=2) -> Tensor:
+    """Everything up to and including the spatial zero-mean (:1315-1346).  Level l works on the input
+    feature map average-pooled l times (floor mode), then is bicubically upsampled back to the INPUT size
+    (the reference hard-codes 128 x 506, :1239-1244) and concatenated; the raw inputs are appended last."""
+    size = tuple(x.shape[-2:])
+    x_in = fluid_layer(sd, "conv.0.", x, act, r_p, use_symm)
+    y = None
+    pooled = x_in
+    for l in range(levels):
+        if l > 0:
+            pooled = F.avg_pool2d(pooled, factor, factor)      # (the reference re-pools x_in l times: same values)
+        cur = pooled
+        for r in range(repeats):
+            cur = fluid_layer(sd, f"convs.{l}.{r}.", cur, act, r_p, use_symm)
+        if l > 0:
+            cur = F.interpolate(cur, size=size, mode="bicubic")
+            y = torch.cat((y, cur), dim=1)
+        else:
+            y = cur
+    y = torch.cat((y, x), dim=1)
+    y = conv2d_same(y, sd["conv.1.weight"], sd["conv.1.bias"], r_p, padding=(1, 1))
+    c = y.shape[1]
+    y = F.group_norm(y, int(c / 4), sd["gn.0.weight"], sd["gn.0.bias"], 1e-5)
+    y = activation(act, y)
+    y = activation(act, conv2d_same(y, sd["conv.2.weight"], sd["conv.2.bias"], r_p, padding=(1, 1)))
+    y = conv2d_same(y, sd["conv.3.weight"], sd["conv.3.bias"], r_p, padding=(1, 1))
+    return y - y.mean(dim=(2, 3), keepdim=True)
+
+
+def newfluidnet_forward(sd, x, *, levels, repeats, act="selu", r_p="zeros", loss_type="mae", use_symm=False,
+                        a_bound=4.0, p_pred=True, factor=2):
+    """Returns (u, v, p) as NewFluidNet.forward (:1348-1390): u, v [B,H,W]; p is [B,1,H,W] for 'mae'/'mass' (the reference
+    returns the un-squeezed slice, :1351-1358) and [B,H,W] for 'curl'; None without p_pred."""
+    y = newfluidnet_features(sd, x, levels=levels, repeats=repeats, act=act, r_p=r_p, use_symm=use_symm, factor=factor)
+    if loss_type in ("mae", "mass"):
+        return y[:, 0], y[:, 1], (y[:, 2:3] if p_pred else None)
+    a = y[:, 0:1] * a_bound
+    p = y[:, 1] if p_pred else None
+    u, v = curl_head(a)
+    return u[:, 0], v[:, 0], p
+
+
+# --------------------------------------------------------------------------------------
 # ConvAE (.ipynb_checkpoints/pycold-checkpoint.py:989-1115)
 # --------------------------------------------------------------------------------------
 def convae_op_table(levels: int, c_i: int, c_h: int, c_o: int, repeats: int) -> list:

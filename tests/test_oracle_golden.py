@@ -106,6 +106,28 @@ def test_unet(golden, tag):
         close(sd[k_].grad, g["grad/" + k_], atol=1e-9)
 
 
+@pytest.mark.parametrize("tag", ["mae_zeros", "curl_rep"])
+def test_newfluidnet(golden, tag):
+    """the multi-resolution trunk (pooled copies of one feature map, bicubic back to 128 x 506, six-way
+    concat with the raw inputs, 3 x 3 head) against the imported reference, outputs and every gradient."""
+    g = golden(f"g12_newfluidnet_{tag}")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm = [int(v) for v in g["cfg"]]
+    sd = sd_from(g)
+    tab = O.newfluidnet_layer_table(levels, c_i, c_h, c_o, repeats)
+    assert len(tab) == sum(1 for k in sd if k.endswith("weight") and sd[k].dim() == 4)
+    x = T(fields.unet_input(1, 128, 506, 121, c_i=c_i), True)
+    outs = O.newfluidnet_forward(sd, x, levels=levels, repeats=repeats, act=str(g["act"]), r_p=str(g["r_p"]),
+                                 loss_type=str(g["loss_type"]), use_symm=bool(symm), p_pred=bool(p_pred))
+    loss = 0.0
+    for n, o in zip("uvp", outs):
+        close(o, g["out/" + n])
+        loss = loss + (o * T(g["ct/" + n])).sum()
+    loss.backward()
+    close(fields.strided_sample(x.grad.numpy(), 1021), g["dx_sample"], atol=1e-10)
+    for k_ in sd:
+        close(sd[k_].grad, g["grad/" + k_], atol=1e-9)
+
+
 @pytest.mark.parametrize("tag", ["mae", "curl"])
 def test_convae(golden, tag):
     g = golden(f"g5_convae_{tag}")

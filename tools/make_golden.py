@@ -372,8 +372,33 @@ def g11():
             loss_type=np.array(loss_type), **sd0, **g0, **sd2)
 
 
+# ------------------------------------------------------------------ G12 NewFluidNet
+def g12():
+    for tag, (loss_type, r_p, symm, act, c_i) in {
+        "mae_zeros": ("mae", "zeros", True, "gelu", 7),
+        "curl_rep": ("curl", "replicate", False, "selu", 7),
+    }.items():
+        m = P.NewFluidNet(3, c_i, 8, 3, CPU, act, r_p, loss_type, use_symm=symm, repeats=2, f=5, p_pred=True).double()
+        randomize_(m, 120)
+        x = torch.from_numpy(fields.unet_input(1, 128, 506, 121, c_i=c_i)).requires_grad_(True)   # the net hard-codes 128 x 506
+        outs = m(x)
+        loss = 0.0
+        save = {}
+        for n, o in zip(["u", "v", "p"], outs):
+            ct = rnd(o.shape, 122 + len(save))
+            loss = loss + (o * ct).sum()
+            save["out/" + n] = o
+            save["ct/" + n] = ct.float()
+        loss.backward()
+        npz(f"g12_newfluidnet_{tag}", dx_sample=fields.strided_sample(x.grad.numpy(), 1021),
+            cfg=np.array([3, c_i, 8, 3, 2, 5, 1, int(symm)]), loss_type=np.array(loss_type), r_p=np.array(r_p),
+            act=np.array(act), **save, **sd_np(m), **grads_np(m))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
-        fn()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+        if not only or fn.__name__ in only:
+            fn()
