@@ -49,7 +49,8 @@ enum { MC_GSRC_NONE = 0,
        MC_GSRC_PLAIN = 1,      /* CB8 tensor of the same H x W                                         */
        MC_GSRC_PADFOLD = 2,    /* dgrad output on the padded domain (H+2p)x(W+2p) whose halo has been      */
                                /* folded onto the interior by mc_fold_padded: read at offset (p, p)    */
-       MC_GSRC_PADFOLD_POOL = 3 /* same, through the adjoint of AvgPool(f): value/f^2 at (y/f, x/f)   */ };
+       MC_GSRC_PADFOLD_POOL = 3, /* same, through the adjoint of AvgPool(f): value/f^2 at (y/f, x/f)  */
+       MC_GSRC_PLAIN_POOL = 4  /* CB8 tensor of size hs x ws through the adjoint of AvgPool(f)        */ };
 
 typedef struct {
   int32_t n;          /* batch                                                       */
@@ -74,6 +75,8 @@ typedef struct {
   int32_t pad_mode;   /* MC_PAD_* of that conv                                        */
   int32_t pool;       /* f for MC_GSRC_PADFOLD_POOL                                   */
   int32_t hs, ws;     /* unpadded spatial size of the tensor `ptr` is the gradient of */
+  int32_t c8_total;   /* > 0: `ptr` holds c8_total channel blocks per sample and this source is   */
+  int32_t cb_off;     /* the slice starting at block cb_off (gradient of one torch.cat operand)   */
 } mc_grad_src;
 
 int mc_version(void);
@@ -171,6 +174,15 @@ int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, in
                               const float* stats_ng2, const float* partials, int32_t blocks, const float* gamma,
                               const float* beta, int32_t act, int32_t dtype, const mc_grad_src* g0,
                               const mc_grad_src* g1, float* dgamma, float* dbeta, void* dy, void* stream);
+
+/* ---- torch.cat of more than two operands along channels (NewFluidNet.forward, pytorch_networks_convae.py:1327-1332):
+ * out [n][sum of blocks][h][w][8]; every operand but the last must have a multiple of 8 channels. */
+int mc_concat_cb8(const void* const* srcs, const int32_t* src_c, int32_t n_src, int32_t n, int32_t h, int32_t w,
+                  int32_t dtype, void* out, void* stream);
+/* out (plain CB8 [n][c/8][h][w][8]) = g0 + g1: materialises the gradient of a tensor with two consumers
+ * (the pooled feature maps of NewFluidNet feed a conv AND the next pooling level). */
+int mc_gsrc_sum(const mc_grad_src* g0, const mc_grad_src* g1, int32_t n, int32_t c, int32_t h, int32_t w,
+                int32_t dtype, void* out, void* stream);
 
 /* ---- resampling (nn.AvgPool2d, nn.Upsample(mode='bicubic'); Unet :2002,2009,2014; ConvAE :1051,1079) */
 int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t f, int32_t dtype,

@@ -14,7 +14,7 @@ MC_F32, MC_BF16 = 0, 1
 PAD_MODES = {"zeros": 0, "constant": 0, "replicate": 1, "reflect": 2}
 ACTS = {"none": 0, "gelu": 1, "relu": 2, "silu": 3, "tanh": 4, "selu": 5, "elu": 6}
 POST_NONE, POST_ACT, POST_GN_ACT = 0, 1, 2
-GSRC_NONE, GSRC_PLAIN, GSRC_PADFOLD, GSRC_PADFOLD_POOL = 0, 1, 2, 3
+GSRC_NONE, GSRC_PLAIN, GSRC_PADFOLD, GSRC_PADFOLD_POOL, GSRC_PLAIN_POOL = 0, 1, 2, 3, 4
 LOSS_SLOTS = 16
 LOSS_TYPES = {"mae": 0, "mass": 1, "curl": 2}
 
@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 class GradSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("kind", C.c_int32), ("pad", C.c_int32), ("pad_mode", C.c_int32),
-                ("pool", C.c_int32), ("hs", C.c_int32), ("ws", C.c_int32)]
+                ("pool", C.c_int32), ("hs", C.c_int32), ("ws", C.c_int32), ("c8_total", C.c_int32), ("cb_off", C.c_int32)]
 
 
 class LossDesc(C.Structure):
@@ -70,6 +70,8 @@ SIGNATURES = {
     "mc_gn_act_bwd_apply_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                             _GS, _GS, _vp, _vp, _vp, _vp]),
     "mc_avgpool_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_concat_cb8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_gsrc_sum": (C.c_int, [_GS, _GS, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_bicubic_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mc_bicubic_bwd": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                  _vp, _vp]),

@@ -264,6 +264,7 @@ __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int 
   const int kind = KIND >= 0 ? KIND : g.kind;
   if (kind == MC_GSRC_NONE || (KIND < 0 && g.ptr == nullptr)) return;
   const T* base = reinterpret_cast<const T*>(g.ptr);
+  if (KIND < 0 && g.c8_total > 0) { C8 = g.c8_total; cb += g.cb_off; }     // slice of a concatenated tensor (generic path only)
   float v[8];
   if (kind == MC_GSRC_PLAIN) {
     V8<T>::ld(base + cb8_index(n, cb, y, x, C8, g.hs, g.ws), v);
@@ -273,12 +274,13 @@ __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int 
   }
   float scale = 1.0f;
   int yy = y, xx = x;
-  if (kind == MC_GSRC_PADFOLD_POOL) {
+  if (kind == MC_GSRC_PADFOLD_POOL || kind == MC_GSRC_PLAIN_POOL) {
     if (g.pool == 2) { yy = y >> 1; xx = x >> 1; } else { yy = y / g.pool; xx = x / g.pool; }
     if (yy >= g.hs || xx >= g.ws) return;   // floor mode: trailing rows/cols are not pooled
     scale = 1.0f / (float)(g.pool * g.pool);
   }
-  V8<T>::ld(base + cb8_index(n, cb, yy + g.pad, xx + g.pad, C8, g.hs + 2 * g.pad, g.ws + 2 * g.pad), v);
+  const int pad = kind == MC_GSRC_PLAIN_POOL ? 0 : g.pad;
+  V8<T>::ld(base + cb8_index(n, cb, yy + pad, xx + pad, C8, g.hs + 2 * pad, g.ws + 2 * pad), v);
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] += scale * v[j];
 }

@@ -258,6 +258,7 @@ template <int GK> struct GKinds {
   static constexpr int k1 = (GK == 1 || GK == 2) ? MC_GSRC_NONE : (GK == 3 ? MC_GSRC_PADFOLD_POOL : -1);
 };
 static int gkind_of(const mc_grad_src& g0, const mc_grad_src& g1) {
+  if (g0.c8_total > 0 || g1.c8_total > 0) return 0;        // slices of a concatenated tensor: generic path
   if (g0.kind == MC_GSRC_PADFOLD && g1.kind == MC_GSRC_NONE) return 1;
   if (g0.kind == MC_GSRC_PLAIN && g1.kind == MC_GSRC_NONE) return 2;
   if (g0.kind == MC_GSRC_PADFOLD && g1.kind == MC_GSRC_PADFOLD_POOL) return 3;
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
       int i = threadIdx.x + m * 256;
       int r = i / BWIN, c = i - r * BWIN;
       bool ok = i < BWIN * BWIN && ylo + r < g.hs && xlo + c < g.ws;
-      const T* p = base + cb8_index(n, cb, min(ylo + r, g.hs - 1) + pad, min(xlo + c, g.ws - 1) + pad, C8, hs, ws);
+      const T* p = base + cb8_index(n, cb + (g.c8_total > 0 ? g.cb_off : 0), min(ylo + r, g.hs - 1) + pad, min(xlo + c, g.ws - 1) + pad,
+                                  g.c8_total > 0 ? g.c8_total : C8, hs, ws);
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p) + 16 * q);
@@ -743,6 +745,34 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
     }
   }
   V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
+}
+
+// =================================================================================================
+// torch.cat along channels of more than two operands; sum of two gradient sources
+// =================================================================================================
+constexpr int CAT_MAX = 12;
+struct CatTable { int n; const void* src[CAT_MAX]; int c8[CAT_MAX]; int first[CAT_MAX + 1]; };
+template <typename T>
+__global__ void k_concat_cb8(CatTable t, int C8, int HW, T* __restrict__ out) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  int k = 0;
+#pragma unroll 1
+  for (int j = 1; j < t.n; ++j) if (cb >= t.first[j]) k = j;
+  const uint4* s = reinterpret_cast<const uint4*>(t.src[k]) + ((size_t)n * t.c8[k] + (cb - t.first[k])) * HW * (sizeof(T) / 2);
+  uint4* d = reinterpret_cast<uint4*>(out) + ((size_t)n * C8 + cb) * HW * (sizeof(T) / 2);
+  const int total = HW * (int)(sizeof(T) / 2);                    // 16-byte pieces per plane
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+template <typename T>
+__global__ void k_gsrc_sum(mc_grad_src g0, mc_grad_src g1, int C8, int H, int W, T* __restrict__ out) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    grad_fetch_add<T>(g0, n, cb, y, x, C8, acc);
+    grad_fetch_add<T>(g1, n, cb, y, x, C8, acc);
+    V8<T>::st(out + cb8_index(n, cb, y, x, C8, H, W), acc);
+  }
 }
 
 // =================================================================================================
@@ -992,13 +1022,15 @@ static int check_gsrc(const mc_grad_src* g) {
   if (!g) return MC_OK;
   if (g->kind == MC_GSRC_NONE) return MC_OK;
   if (!g->ptr || g->hs <= 0 || g->ws <= 0) return MC_EINVAL;
-  if (g->kind == MC_GSRC_PADFOLD_POOL && g->pool < 1) return MC_EINVAL;
-  if (g->kind != MC_GSRC_PLAIN && (g->pad < 0 || g->pad > 2)) return MC_EUNSUPPORTED;
+  if (g->kind < MC_GSRC_NONE || g->kind > MC_GSRC_PLAIN_POOL) return MC_EINVAL;
+  if ((g->kind == MC_GSRC_PADFOLD_POOL || g->kind == MC_GSRC_PLAIN_POOL) && g->pool < 1) return MC_EINVAL;
+  if ((g->kind == MC_GSRC_PADFOLD || g->kind == MC_GSRC_PADFOLD_POOL) && (g->pad < 0 || g->pad > 2)) return MC_EUNSUPPORTED;
+  if (g->c8_total < 0 || g->cb_off < 0 || (g->c8_total > 0 && g->cb_off >= g->c8_total)) return MC_EINVAL;
   return MC_OK;
 }
 static mc_grad_src gsrc_or_none(const mc_grad_src* g) {
   mc_grad_src z;
-  z.ptr = nullptr; z.kind = MC_GSRC_NONE; z.pad = 0; z.pad_mode = 0; z.pool = 1; z.hs = 0; z.ws = 0;
+  z.ptr = nullptr; z.kind = MC_GSRC_NONE; z.pad = 0; z.pad_mode = 0; z.pool = 1; z.hs = 0; z.ws = 0; z.c8_total = 0; z.cb_off = 0;
   return g ? *g : z;
 }
 
@@ -1086,6 +1118,44 @@ int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, true>), g, dim3(256), 0, s, a, (const float*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, partials, blocks, dgamma, dbeta, rows);
   else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, true>), g, dim3(256), 0, s, a, (const bf16_t*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, partials, blocks, dgamma, dbeta, rows);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_concat_cb8(const void* const* srcs, const int32_t* src_c, int32_t n_src, int32_t n, int32_t h, int32_t w,
+                  int32_t dtype, void* out, void* stream) {
+  if (!srcs || !src_c || !out || n_src < 1 || n_src > CAT_MAX || n <= 0 || h <= 0 || w <= 0) return MC_EINVAL;
+  CatTable t;
+  t.n = n_src;
+  int C8 = 0;
+  for (int k = 0; k < n_src; ++k) {
+    if (!srcs[k] || src_c[k] <= 0) return MC_EINVAL;
+    if (k < n_src - 1 && (src_c[k] % 8) != 0) return MC_EUNSUPPORTED;      // only the last operand may end in a partial block
+    t.src[k] = srcs[k]; t.c8[k] = (src_c[k] + 7) / 8; t.first[k] = C8;
+    C8 += t.c8[k];
+  }
+  t.first[n_src] = C8;
+  hipStream_t s = (hipStream_t)stream;
+  const int per = h * w * (dtype == MC_F32 ? 2 : 1);
+  dim3 g(max(1, min(cdiv(per, 256 * 4), 1024)), C8, n);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_concat_cb8<float>, g, dim3(256), 0, s, t, C8, h * w, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_concat_cb8<bf16_t>, g, dim3(256), 0, s, t, C8, h * w, (bf16_t*)out);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gsrc_sum(const mc_grad_src* g0, const mc_grad_src* g1, int32_t n, int32_t c, int32_t h, int32_t w,
+                int32_t dtype, void* out, void* stream) {
+  if (!g0 || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0) return MC_EINVAL;
+  int rc;
+  if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
+  const int C8 = (c + 7) / 8;
+  dim3 g(max(1, min(cdiv(h * w, 256 * 4), 1024)), C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_gsrc_sum<float>, g, dim3(256), 0, s, gsrc_or_none(g0), gsrc_or_none(g1), C8, h, w, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gsrc_sum<bf16_t>, g, dim3(256), 0, s, gsrc_or_none(g0), gsrc_or_none(g1), C8, h, w, (bf16_t*)out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;

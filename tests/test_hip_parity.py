@@ -125,3 +125,52 @@ def test_convae_golden(golden, tag):
         ref = g["grad/" + n]
         scale = max(1.0, float(np.abs(ref).max()))
         assert_close(p.grad, ref, atol=2e-4 * scale, rtol=1e-3, what=n)
+
+
+def test_concat_and_gradient_source_kinds():
+    """mc_concat_cb8 (torch.cat of > 2 operands), mc_gsrc_sum, slices of a concatenated gradient and the AvgPool adjoint of a
+    plain tensor (SURVEY 8f N1 plumbing) against torch."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from pbml_mantle_convection_amd import _lib as L
+    L.load()
+    st = L.stream()
+    N, H, W = 2, 9, 13
+    g = torch.Generator().manual_seed(5)
+    chans = [8, 16, 8, 5]
+
+    def to_cb8(t):                                                   # NCHW f32 -> CB8 f32 [N][C8][H][W][8]
+        n, c, h, w = t.shape
+        c8 = (c + 7) // 8
+        p = torch.zeros((n, c8 * 8, h, w))
+        p[:, :c] = t
+        return p.view(n, c8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+
+    def from_cb8(t, c):
+        n, c8, h, w, _ = t.shape
+        return t.permute(0, 1, 4, 2, 3).reshape(n, c8 * 8, h, w)[:, :c].cpu()
+
+    xs = [torch.randn((N, c, H, W), generator=g) for c in chans]
+    bufs = [to_cb8(x) for x in xs]
+    c8s = [(c + 7) // 8 for c in chans]
+    out = torch.empty((N, sum(c8s), H, W, 8), device=DEV)
+    srcs = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+    cs = (C.c_int32 * len(bufs))(*chans)
+    L.call("mc_concat_cb8", srcs, cs, len(bufs), N, H, W, L.MC_F32, L.ptr(out), st)
+    cat = from_cb8(out, sum(c8s) * 8)
+    off = 0
+    for x, c8 in zip(xs, c8s):
+        assert torch.equal(cat[:, off * 8:off * 8 + x.shape[1]], x)
+        off += c8
+    # gradient sources: slice 1 (16 channels at block 1) of the concatenated tensor + AvgPool(2) adjoint of a plain tensor
+    low = torch.randn((N, 16, H // 2, W // 2), generator=g)
+    lowb = to_cb8(low)
+    g0 = L.GradSrc(L.ptr(out), L.GSRC_PLAIN, 0, 0, 1, H, W, sum(c8s), 1)
+    g1 = L.GradSrc(L.ptr(lowb), L.GSRC_PLAIN_POOL, 0, 0, 2, H // 2, W // 2, 0, 0)
+    res = torch.empty((N, 2, H, W, 8), device=DEV)
+    L.call("mc_gsrc_sum", C.byref(g0), C.byref(g1), N, 16, H, W, L.MC_F32, L.ptr(res), st)
+    xp = low.clone().requires_grad_(True)
+    up = torch.zeros((N, 16, H, W))
+    up[:, :, :2 * (H // 2), :2 * (W // 2)] = F.interpolate(low, scale_factor=2, mode="nearest") / 4.0   # adjoint of AvgPool(2), floor mode
+    ref = xs[1] + up
+    torch.testing.assert_close(from_cb8(res, 16), ref, rtol=1e-6, atol=1e-6)
