@@ -57,6 +57,21 @@ class UpNode:
 
 
 @dataclass
+class PoolNode:                 # standalone nn.AvgPool2d(f, stride=f) (floor mode)
+    src: int
+    out: int
+    f: int
+    kind: str = "pool"
+
+
+@dataclass
+class CatNode:                  # torch.cat of several tensors along channels (every operand but the last: C % 8 == 0)
+    srcs: List[int]
+    out: int
+    kind: str = "cat"
+
+
+@dataclass
 class NetGraph:
     c_in: int
     c_out: int
@@ -198,6 +213,56 @@ def convae_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, loss_
     return NetGraph(c_i, int(c_o), ch, nodes, pad_mode=r_p, act=act, divisor=4 ** levels)
 
 
+def newfluidnet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, factor=2) -> NetGraph:
+    """Layer wiring of NewFluidNet.__init__/forward (reference pytorch_networks_convae.py:1215-1346): level l = the input
+    feature map average-pooled l times, `repeats` FluidLayers, bicubic back to the input size; six-way concat with the raw
+    inputs; 3 x 3 head.  The reference re-pools the feature map from scratch for every level; the values are identical to
+    pooling the previous level once more, which is what the graph does."""
+    if c_h % 8:
+        raise NotImplementedError("the HIP path of NewFluidNet needs c_h to be a multiple of 8 (channel-block concat)")
+    ch: Dict[int, int] = {0: c_i}
+    nodes = []
+    nid = [0]
+
+    def new(c):
+        nid[0] += 1
+        ch[nid[0]] = c
+        return nid[0]
+
+    def fluid(prefix, src, c_out):
+        out = new(c_out)
+        node = ConvNode(prefix + "layers.0.", [src], out, c_out, f, f // 2, _sym_h(c_out) if use_symm else 0,
+                        L.POST_GN_ACT, prefix + "layers.1.", _groups(c_out))
+        nodes.append(node)
+        return node
+
+    x_in = fluid("conv.0.", 0, c_h).out
+    pooled = x_in
+    outs = []
+    for l in range(levels):
+        if l > 0:
+            p = new(c_h)
+            nodes.append(PoolNode(pooled, p, factor))
+            pooled = p
+        cur = pooled
+        for r in range(repeats):
+            cur = fluid(f"convs.{l}.{r}.", cur, c_h).out
+        if l > 0:
+            up = new(c_h)
+            nodes.append(UpNode(cur, up, like=x_in))
+            cur = up
+        outs.append(cur)
+    cat = new(c_h * levels + c_i)
+    nodes.append(CatNode(outs + [0], cat))
+    o = new(c_h)
+    nodes.append(ConvNode("conv.1.", [cat], o, c_h, 3, 1, 0, L.POST_GN_ACT, "gn.0.", int(c_h / 4)))
+    o2 = new(c_h)
+    nodes.append(ConvNode("conv.2.", [o], o2, c_h, 3, 1, 0, L.POST_ACT, None, 1))
+    o3 = new(c_o)
+    nodes.append(ConvNode("conv.3.", [o2], o3, c_o, 3, 1, 0, L.POST_NONE, None, 1))
+    return NetGraph(c_i, c_o, ch, nodes, subtract_mean=True, pad_mode=r_p, act=act, divisor=1)
+
+
 def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool) -> NetGraph:
     """One conv (+GN+act): SymmetricConv2d / FluidLayer used stand-alone."""
     ch = {0: c_in, 1: c_out}
@@ -306,6 +371,22 @@ class Engine:
                 tabs = (self._table(s.H, ho), self._table(s.W, wo))
                 self.plan.append(dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W)))
                 continue
+            if node.kind == "pool":
+                s, o = T[node.src], T[node.out]
+                o.H, o.W = s.H // node.f, s.W // node.f
+                o.buf = cb8(o.C, o.H, o.W)
+                o.requires_grad = s.requires_grad
+                self.plan.append(dict(node=node, dsum=cb8(o.C, o.H, o.W)))
+                continue
+            if node.kind == "cat":
+                srcs = [T[i] for i in node.srcs]
+                o = T[node.out]
+                o.H, o.W = srcs[0].H, srcs[0].W
+                if any((t.H, t.W) != (o.H, o.W) for t in srcs) or any(t.C % 8 for t in srcs[:-1]):
+                    raise ValueError("torch.cat operands must share H x W and all but the last need C % 8 == 0")
+                o.buf = cb8(o.C, o.H, o.W)
+                self.plan.append(dict(node=node))
+                continue
             srcs = [T[i] for i in node.srcs]
             h, w = srcs[0].H, srcs[0].W
             for s in srcs:
@@ -409,6 +490,17 @@ class Engine:
             self._pack_all_banks(params, st)
         for e in self.plan:
             node = e["node"]
+            if node.kind == "pool":
+                s, o = T[node.src], T[node.out]
+                L.call("mc_avgpool_fwd", L.ptr(s.buf), N, s.C, s.H, s.W, node.f, self.mc_dtype, L.ptr(o.buf), st)
+                continue
+            if node.kind == "cat":
+                srcs = [T[i] for i in node.srcs]
+                o = T[node.out]
+                ptrs = (C.c_void_p * len(srcs))(*[L.ptr(t.buf) for t in srcs])
+                cs = (C.c_int32 * len(srcs))(*[t.C for t in srcs])
+                L.call("mc_concat_cb8", ptrs, cs, len(srcs), N, o.H, o.W, self.mc_dtype, L.ptr(o.buf), st)
+                continue
             if node.kind == "up":
                 s, o = T[node.src], T[node.out]
                 (iy, wy, *_), (ix, wx, *_) = e["tabs"]
@@ -483,6 +575,33 @@ class Engine:
             fo.gsrcs.append(L.GradSrc(L.ptr(self.dOut), L.GSRC_PLAIN, 0, 0, 1, fo.H, fo.W))
         for e in reversed(self.plan):
             node = e["node"]
+            if node.kind == "cat":
+                # the gradient of the concatenated tensor is one buffer; every operand reads its channel-block slice
+                o = T[node.out]
+                assert len(o.gsrcs) == 1, "a concatenated tensor feeds exactly one conv"
+                q = o.gsrcs[0]
+                c8_total = (o.C + 7) // 8
+                off = 0
+                for i in node.srcs:
+                    t = T[i]
+                    if t.requires_grad:
+                        t.gsrcs.append(L.GradSrc(q.ptr, q.kind, q.pad, q.pad_mode, q.pool, q.hs, q.ws, c8_total, off))
+                    off += (t.C + 7) // 8
+                continue
+            if node.kind == "pool":
+                # d(src) += AvgPool adjoint of d(out); d(out) has one source (the conv it feeds) or two (+ the next pooling level)
+                s, o = T[node.src], T[node.out]
+                assert 1 <= len(o.gsrcs) <= 2
+                if not s.requires_grad:
+                    continue
+                q = o.gsrcs[0]
+                if len(o.gsrcs) == 1 and q.kind == L.GSRC_PADFOLD and q.c8_total == 0:
+                    s.gsrcs.append(L.GradSrc(q.ptr, L.GSRC_PADFOLD_POOL, q.pad, q.pad_mode, node.f, o.H, o.W))
+                else:
+                    g1 = C.byref(o.gsrcs[1]) if len(o.gsrcs) > 1 else None
+                    L.call("mc_gsrc_sum", C.byref(q), g1, N, o.C, o.H, o.W, self.mc_dtype, L.ptr(e["dsum"]), st)
+                    s.gsrcs.append(L.GradSrc(L.ptr(e["dsum"]), L.GSRC_PLAIN_POOL, 0, 0, node.f, o.H, o.W))
+                continue
             if node.kind == "up":
                 s, o = T[node.src], T[node.out]
                 assert len(o.gsrcs) == 1, "an upsampled tensor feeds exactly one conv"

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 import torch.optim as optim
 
 from . import _lib as L
-from .engine import convae_graph, single_layer_graph, unet_graph
+from .engine import convae_graph, newfluidnet_graph, single_layer_graph, unet_graph
 from .hipnet import HipNetMixin
 from .symmetric_layers_torch import SymmetricConv2d
 
@@ -268,6 +268,92 @@ class Unet(nn.Module, HipNetMixin):
             u, v, T = _CurlHead.apply(y, self.a_bound)
             p = y[:, 2] if self.p_pred else None
             return u, v, p, T
+        raise ValueError(self.loss_type)
+
+
+# --------------------------------------------------------------------------------------------------
+# NewFluidNet (reference :1068-1390) — SURVEY.md §8(f) row N1
+# --------------------------------------------------------------------------------------------------
+class _CurlUV(torch.autograd.Function):
+    """u, v from the streamfunction channel with antisymmetric walls and zero corners (:1360-1388); no T channel."""
+
+    @staticmethod
+    def forward(ctx, y, a_bound):
+        N, Cc, H, W = y.shape
+        y = y.contiguous()
+        u = torch.empty((N, H, W), dtype=torch.float32, device=y.device)
+        v = torch.empty_like(u)
+        L.call("mc_curl_head_fwd", L.ptr(y), None, N, H, W, Cc * H * W, float(a_bound), 0.0, 0.0, L.ptr(u), L.ptr(v), None,
+               L.stream())
+        ctx.shape, ctx.a_bound = (N, Cc, H, W), float(a_bound)
+        return u, v
+
+    @staticmethod
+    def backward(ctx, gu, gv):
+        N, Cc, H, W = ctx.shape
+        dev = gu.device if gu is not None else gv.device
+        gy = torch.zeros((N, Cc, H, W), dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * N * (H - 2) * (W - 2), dtype=torch.float32, device=dev)
+        gu = (gu if gu is not None else torch.zeros((N, H, W), device=dev)).contiguous().float()
+        gv = (gv if gv is not None else torch.zeros((N, H, W), device=dev)).contiguous().float()
+        L.call("mc_curl_head_bwd", L.ptr(gu), L.ptr(gv), None, None, N, H, W, ctx.a_bound, 0.0, 0.0, L.ptr(gy), None,
+               Cc * H * W, Cc * H * W, L.ptr(ws), L.stream())
+        return gy, None
+
+
+class NewFluidNet(nn.Module, HipNetMixin):
+    """Multi-resolution trunk of the deployed surrogate (`-net newfluidnet -l 5 -f 16 -r 6 -k 5`): level l works on the first
+    feature map average-pooled l times, is bicubically upsampled back and concatenated with the others and the raw inputs.
+    Same constructor, module tree and state_dict keys as the reference; forward returns (u, v, p).  The reference
+    hard-codes the 128 x 506 grid in its Upsample modules (:1239-1244); here the levels are upsampled to the input's size."""
+
+    def __init__(self, levels: int, c_i: int, c_h: int, c_o: int, device=None, act_fn: str = "selu", r_p="zeros",
+                 loss_type="mae", use_symm=False, dilation=1, a_bound=4.0, use_cosine=False, repeats=3, use_skip=False,
+                 f=3, p_pred=True, spectral_conv=False, blurr=False, drop_rate=0.0, factor=2):
+        super().__init__()
+        _check_common(act_fn, r_p, dilation, drop_rate, spectral_conv, blurr)
+        self.levels, self.loss_type, self.a_bound = levels, loss_type, a_bound
+        self.use_cosine, self.repeats, self.use_skip, self.p_pred = use_cosine, repeats, use_skip, p_pred
+        self.c_h, self.c_i, self.c_o = c_h, c_i, c_o
+        self.blurrer = None
+        self.r_p = "constant" if r_p == "zeros" else r_p
+        graph = newfluidnet_graph(levels, c_i, c_h, c_o, act=act_fn, r_p=r_p, use_symm=use_symm, repeats=repeats, f=f,
+                                  factor=factor)
+
+        def fl(cin, cout):
+            return FluidLayer(cin, cout, act_fn, r_p, use_symm, dilation, f=f, drop_rate=drop_rate)
+
+        # module tree in the reference's construction order (:1148-1313) so state_dict keys match
+        self.conv = nn.ModuleList()
+        self.gn = nn.ModuleList()
+        self.unpool = nn.ModuleList()
+        self.conv.append(fl(c_i, c_h))
+        self.pool = nn.AvgPool2d((factor, factor), stride=factor)
+        for _ in range(1, levels):
+            self.unpool.append(nn.Upsample(size=(128, 506), mode="bicubic"))
+        self.convs = nn.ModuleList()
+        for l in range(levels):
+            self.convs.append(nn.ModuleList())
+            for r in range(repeats):
+                self.convs[l].append(fl(c_h, c_h))
+        self.conv.append(nn.Conv2d(c_h * levels + c_i, c_h, kernel_size=3, padding=(1, 1), dilation=dilation, padding_mode=r_p))
+        self.gn.append(torch.nn.GroupNorm(int(c_h / 4), c_h))
+        self.conv.append(nn.Conv2d(c_h, c_h, kernel_size=3, padding=(1, 1), padding_mode=r_p))
+        self.conv.append(nn.Conv2d(c_h, c_o, kernel_size=3, padding=(1, 1), padding_mode=r_p))
+        self._init_hipnet(graph)
+
+    def features(self, inputs):
+        """y - mean_HW(y): everything up to the output heads (:1315-1346)."""
+        return self._run_graph(inputs)
+
+    def forward(self, inputs):
+        y = self.features(inputs)
+        if self.loss_type in ("mae", "mass"):
+            # (the reference returns p un-squeezed, [B,1,H,W], :1351-1358)
+            return y[:, 0], y[:, 1], (y[:, 2:3] if self.p_pred else None)
+        elif self.loss_type == "curl":
+            u, v = _CurlUV.apply(y, self.a_bound)
+            return u, v, (y[:, 1] if self.p_pred else None)
         raise ValueError(self.loss_type)
 
 
