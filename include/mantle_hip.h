@@ -221,9 +221,11 @@ typedef struct {
   float lambda_mom;        /* weight of the momentum residual term (0 = off)               */
   float inv_h;             /* 1/h of the momentum residual (126)                           */
   float ra;                /* Rayleigh number in the buoyancy term (1)                     */
-  int32_t t_grad;          /* 1: T is a network output (gets a gradient)                   */
+  int32_t t_grad;          /* 1: T is a network output (gets a gradient); 0: T is given;   */
+                           /* -1: the network has no temperature output (FluidNet family,  */
+                           /* multigpu.py:138-195): T / gT may be NULL, uvp is (u, v[, p]) */
 } mc_loss_desc;
-/* per-sample min/max of truth u,v over (H,W): mm [n][2][2] */
+/* per-sample (min, max) over (H,W) of the truth channels u, v and (when ct >= 3) channel 2: mm [n][3][2] */
 int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w, float* mm, void* stream);
 /* Fused forward + backward of the data / derivative / divergence terms.  u,v,p,T: predictions
  * [n][h][w] f32 with the given batch strides (p may be NULL); sums: MC_LOSS_SLOTS doubles

@@ -612,6 +612,41 @@ def get_loss_unet(pred: Tuple[Tensor, Tensor, Optional[Tensor], Tensor], uvp: Te
     return tuple(out)
 
 
+def get_loss_fluidnet(pred: Tuple[Tensor, Tensor, Optional[Tensor]], uvp: Tensor, *, p_pred: bool, loss_type: str,
+                      loss_scale: bool = False, loss_derivative: bool = False, norm: str = "l1"):
+    """The 'fluidnet' branch of Trainer.get_loss (multigpu.py:138-195, model_AD None) given the network outputs
+    (u, v, p): no temperature term, averaging over 3 (2) terms, and — unlike the Unet branch — the SCALED pressure loss
+    (`loss_p, _ = self.loss_fn(p_true, p)`, :146-148).  Predictions are squeezed to [B,H,W] (the 'mae' head returns p
+    un-squeezed, which would broadcast against the [B,H,W] truth).  Returns the reference's 6-tuple, loss_T = 0."""
+    u, v, p = pred
+    B = uvp.shape[0]
+    H, W = uvp.shape[-2:]
+    u = u.reshape(B, H, W)
+    v = v.reshape(B, H, W)
+    u_true, v_true = uvp[:, 0], uvp[:, 1]
+    loss_u, true_u = loss_fn(u_true, u, loss_scale, norm)
+    loss_v, true_v = loss_fn(v_true, v, loss_scale, norm)
+    if p_pred:
+        loss_p, _ = loss_fn(uvp[:, 2], p.reshape(B, H, W), loss_scale, norm)
+    else:
+        loss_p = torch.zeros((), dtype=u.dtype)
+    if loss_derivative:
+        u4, v4 = u.reshape(B, 1, H, W), v.reshape(B, 1, H, W)
+        ut4, vt4 = u_true.reshape(B, 1, H, W), v_true.reshape(B, 1, H, W)
+        loss_u = loss_u + (dy_top(ut4) * 126 - dy_top(u4) * 126).abs().mean()
+        loss_v = loss_v + (dx_left(vt4) * 126 - dx_left(v4) * 126).abs().mean()
+        if not loss_scale:
+            true_u, true_v = loss_u, loss_v            # the same in-place aliasing quirk as the Unet branch (:168-169)
+    mass = divergence_abs(u, v)
+    loss = (loss_u + loss_v + loss_p) / 3.0 if p_pred else (loss_u + loss_v) / 2.0
+    if loss_type == "mass":
+        loss = loss + mass.mean()
+    elif loss_type == "curl":
+        loss = loss + (mass[:, :, :, 0].mean() + mass[:, :, :, -1].mean()
+                       + mass[:, :, 0, :].mean() + mass[:, :, -1, :].mean())
+    return loss, true_u, true_v, loss_p, torch.zeros((), dtype=u.dtype), mass.mean()
+
+
 # --------------------------------------------------------------------------------------
 # Stokes momentum residual — BUILD-DEFINED (SURVEY.md row A12; no reference implementation)
 # --------------------------------------------------------------------------------------

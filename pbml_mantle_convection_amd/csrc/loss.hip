@@ -32,7 +32,7 @@ struct BlockSums {
 };
 
 __global__ void k_minmax(const float* __restrict__ uvp, int ct, int hw, float* __restrict__ mm) {
-  const int n = blockIdx.x, f = blockIdx.y;  // f = 0 (u) or 1 (v)
+  const int n = blockIdx.x, f = blockIdx.y;  // f = 0 (u), 1 (v) or 2 (p: FluidNet mode scales the pressure term too)
   const float* p = uvp + ((size_t)n * ct + f) * hw;
   float lo = 3.4e38f, hi = -3.4e38f;
   for (int i = threadIdx.x; i < hw; i += blockDim.x) { float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
@@ -41,8 +41,8 @@ __global__ void k_minmax(const float* __restrict__ uvp, int ct, int hw, float* _
   if ((threadIdx.x & 63) == 0) { rl[threadIdx.x >> 6] = lo; rh[threadIdx.x >> 6] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    mm[(n * 2 + f) * 2 + 0] = fminf(fminf(rl[0], rl[1]), fminf(rl[2], rl[3]));
-    mm[(n * 2 + f) * 2 + 1] = fmaxf(fmaxf(rh[0], rh[1]), fmaxf(rh[2], rh[3]));
+    mm[(n * 3 + f) * 2 + 0] = fminf(fminf(rl[0], rl[1]), fminf(rl[2], rl[3]));
+    mm[(n * 3 + f) * 2 + 1] = fmaxf(fmaxf(rh[0], rh[1]), fmaxf(rh[2], rh[3]));
   }
 }
 
@@ -79,19 +79,24 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
   const float* u = u_ + (size_t)n * g.pbs;
   const float* v = v_ + (size_t)n * g.pbs;
   const float* p = p_ ? p_ + (size_t)n * g.ppbs : nullptr;
-  const float* T = T_ + (size_t)n * g.pbs;
+  const bool hasT = g.d.t_grad >= 0;                              // FluidNet family: no temperature output
+  const float* T = hasT ? T_ + (size_t)n * g.pbs : nullptr;
   const float* ut = uvp + ((size_t)n * g.ct + 0) * HW;
   const float* vt = uvp + ((size_t)n * g.ct + 1) * HW;
   const float* pt = g.d.p_pred ? uvp + ((size_t)n * g.ct + 2) * HW : nullptr;
-  const float* Tt = uvp + ((size_t)n * g.ct + (g.d.p_pred ? 3 : 2)) * HW;
-  const float k = g.d.p_pred ? 4.f : 3.f;
+  const float* Tt = hasT ? uvp + ((size_t)n * g.ct + (g.d.p_pred ? 3 : 2)) * HW : nullptr;
+  const float k = (g.d.p_pred ? 3.f : 2.f) + (hasT ? 1.f : 0.f);
   const float NHW = (float)g.d.n * (float)HW;
   const float cdat = 1.0f / (k * NHW);
   float su = 1.f, sv = 1.f;
   if (g.d.loss_scale) {
-    su = fminf(fmaxf(1.0f / (mm[(n * 2 + 0) * 2 + 1] - mm[(n * 2 + 0) * 2 + 0]), 1.0f), 10.0f);
-    sv = fminf(fmaxf(1.0f / (mm[(n * 2 + 1) * 2 + 1] - mm[(n * 2 + 1) * 2 + 0]), 1.0f), 10.0f);
+    su = fminf(fmaxf(1.0f / (mm[(n * 3 + 0) * 2 + 1] - mm[(n * 3 + 0) * 2 + 0]), 1.0f), 10.0f);
+    sv = fminf(fmaxf(1.0f / (mm[(n * 3 + 1) * 2 + 1] - mm[(n * 3 + 1) * 2 + 0]), 1.0f), 10.0f);
   }
+  // FluidNet branch of get_loss keeps the SCALED pressure loss (`loss_p, _ = self.loss_fn(p_true, p)`, multigpu.py:146-148);
+  // the Unet branch keeps the plain one (:262-266)
+  const bool p_scaled = !hasT && g.d.loss_scale && g.d.p_pred;
+  const float sp = p_scaled ? fminf(fmaxf(1.0f / (mm[(n * 3 + 2) * 2 + 1] - mm[(n * 3 + 2) * 2 + 0]), 1.0f), 10.0f) : 1.f;
   const float cdu = 126.0f / (k * (float)g.d.n * (float)(H - 2) * (float)W);
   const float cdv = 126.0f / (k * (float)g.d.n * (float)H * (float)(W - 2));
   double a_us = 0, a_up = 0, a_vs = 0, a_vp = 0, a_pp = 0, a_tp = 0, a_du = 0, a_dv = 0;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
     const float bw = (g.d.loss_scale && (y < 2 || y >= H - 2 || x < 2 || x >= W - 2)) ? 11.f : 1.f;
     float gu = 0.f, gv = 0.f, gp = 0.f, gT = 0.f;
     {  // data terms
-      float du = ut[i] - u[i], dv = vt[i] - v[i], dT = Tt[i] - T[i];
+      float du = ut[i] - u[i], dv = vt[i] - v[i], dT = hasT ? Tt[i] - T[i] : 0.f;
       float wu = su * bw, wv = sv * bw;
       if (!g.d.l2) {
         a_us += fabsf(du * wu); a_up += fabsf(du);
@@ -117,8 +122,9 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
       }
       if (p) {
         float dp = pt[i] - p[i];
-        if (!g.d.l2) { a_pp += fabsf(dp); gp -= sgn(dp) * cdat; }
-        else { a_pp += (double)dp * dp; gp -= 2.f * dp * cdat; }
+        const float wp = p_scaled ? sp * bw : 1.f;
+        if (!g.d.l2) { a_pp += fabsf(dp * wp); gp -= sgn(dp) * wp * cdat; }
+        else { a_pp += (double)(dp * wp) * (dp * wp); gp -= 2.f * dp * wp * wp * cdat; }
       }
     }
     if (g.d.loss_derivative) {
@@ -295,7 +301,8 @@ __global__ void k_loss_finalize(mc_loss_desc d, const double* __restrict__ s, fl
     lv += s[MC_S_DV] / (N * H * (W - 2));
     if (!d.loss_scale) { tu = lu; tv = lv; }   // reference aliasing quirk (multigpu.py:283-284)
   }
-  double loss = d.p_pred ? (lu + lv + lp + lT) / 4.0 : (lu + lv + lT) / 3.0;
+  if (d.t_grad < 0) lT = 0.0;                                     // no temperature output: averaged over 3 / 2 terms (multigpu.py:173-177)
+  double loss = (lu + lv + lp + lT) / ((d.p_pred ? 3.0 : 2.0) + (d.t_grad < 0 ? 0.0 : 1.0));
   double mass = s[MC_S_MASS] / (N * (H - 2) * (W - 2));
   if (d.loss_type == 1) loss += mass;
   else if (d.loss_type == 2)
@@ -327,7 +334,7 @@ extern "C" {
 
 int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w, float* mm, void* stream) {
   if (!uvp || !mm || n <= 0 || ct < 2 || h <= 0 || w <= 0) return MC_EINVAL;
-  hipLaunchKernelGGL(k_minmax, dim3(n, 2), dim3(256), 0, (hipStream_t)stream, uvp, ct, h * w, mm);
+  hipLaunchKernelGGL(k_minmax, dim3(n, ct >= 3 ? 3 : 2), dim3(256), 0, (hipStream_t)stream, uvp, ct, h * w, mm);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -337,14 +344,15 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
                     float* gp, float* gT, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
-  if (!u || !v || !T || !uvp || !sums || !gu || !gv || !gT) return MC_EINVAL;
+  const bool hasT = d->t_grad >= 0;
+  if (!u || !v || !uvp || !sums || !gu || !gv || (hasT && (!T || !gT))) return MC_EINVAL;
   if (d->p_pred && (!p || !gp)) return MC_EINVAL;
   if (d->loss_scale && !mm) return MC_EINVAL;
   LossGeom g;
-  g.d = *d; g.ct = d->p_pred ? 4 : 3; g.pbs = pbs; g.ppbs = ppbs;
+  g.d = *d; g.ct = (d->p_pred ? 3 : 2) + (hasT ? 1 : 0); g.pbs = pbs; g.ppbs = ppbs;
   dim3 grid(loss_blocks(d->h * d->w, d->n), d->n);
   hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
-                     gu, gv, d->p_pred ? gp : nullptr, gT);
+                     gu, gv, d->p_pred ? gp : nullptr, hasT ? gT : nullptr);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -354,7 +362,7 @@ int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, 
                          double* sums, float* sx, float* sy, float* eta_ws, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
-  if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy || !eta_ws) return MC_EINVAL;
+  if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy || !eta_ws || d->t_grad < 0) return MC_EINVAL;
   MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
   dim3 grid(loss_blocks(d->h * d->w, d->n), d->n);
   hipLaunchKernelGGL(k_mom_eta, grid, dim3(256), 0, (hipStream_t)stream, d->h * d->w, pbs, T, yc, paras, eta_ws);

@@ -38,7 +38,7 @@ class StokesLoss:
         f32 = dict(dtype=torch.float32, device=dev)
         self.sums = torch.zeros(L.LOSS_SLOTS, dtype=torch.float64, device=dev)
         self.out8 = torch.zeros(8, **f32)
-        self.mm = torch.zeros((N, 2, 2), **f32)
+        self.mm = torch.zeros((N, 3, 2), **f32)
         self.gy = torch.zeros((N, Cc, H, W), **f32)
         if self.loss_type == "curl":
             self.cu, self.cv, self.cT = (torch.empty((N, H, W), **f32) for _ in range(3))

@@ -170,6 +170,29 @@ def test_get_loss_table(golden):
             close(fields.strided_sample(p.grad.numpy()), g[f"dp/{case}"], atol=1e-14)
 
 
+def test_get_loss_fluidnet_table(golden):
+    """the FluidNet branch of get_loss (no T term, scaled pressure loss), 24 cases with gradients."""
+    g = golden("g13_get_loss_fluidnet")
+    B, H, W = 2, 128, 506
+    for case, row in enumerate(g["table"]):
+        p_pred, lt, ls, ld, seed = [int(v) for v in row[:5]]
+        u = T(fields.smooth_field(B, H, W, seed + 1, noise=0.01), True)
+        v = T(fields.smooth_field(B, H, W, seed + 2, noise=0.01), True)
+        p = T(fields.smooth_field(B, H, W, seed + 3, amp=0.5), True)
+        truth = [fields.smooth_field(B, H, W, seed + 5), fields.smooth_field(B, H, W, seed + 6)]
+        if p_pred:
+            truth.append(fields.smooth_field(B, H, W, seed + 7, amp=0.5))
+        uvp = T(np.stack(truth, 1))
+        out = O.get_loss_fluidnet((u, v, p if p_pred else None), uvp, p_pred=bool(p_pred),
+                                  loss_type=["mae", "mass", "curl"][lt], loss_scale=bool(ls), loss_derivative=bool(ld))
+        close(torch.stack([o.detach() for o in out]), row[5:], rtol=1e-10)
+        out[0].backward()
+        close(fields.strided_sample(u.grad.numpy()), g[f"du/{case}"], atol=1e-14)
+        close(fields.strided_sample(v.grad.numpy()), g[f"dv/{case}"], atol=1e-14)
+        if p_pred:
+            close(fields.strided_sample(p.grad.numpy()), g[f"dp/{case}"], atol=1e-14)
+
+
 def test_loss_fn(golden):
     g = golden("g6b_loss_fn")
     for ls in (0, 1):

@@ -395,10 +395,52 @@ def g12():
             act=np.array(act), **save, **sd_np(m), **grads_np(m))
 
 
+# ------------------------------------------------------------------ G13 get_loss, FluidNet branch (multigpu.py:138-195)
+class _Stub3(torch.nn.Module):
+    def __init__(self, u, v, p):
+        super().__init__()
+        self.o = (u, v, p)
+
+    def forward(self, x):
+        return self.o
+
+
+def g13():
+    B, H, W = 2, 128, 506
+    rows, samples, case = [], {}, 0
+    for p_pred in (True, False):
+        for loss_type in ("mae", "mass", "curl"):
+            for loss_scale in (False, True):
+                for loss_derivative in (False, True):
+                    seed = 1300 + case
+                    u = torch.from_numpy(fields.smooth_field(B, H, W, seed + 1, noise=0.01)).requires_grad_(True)
+                    v = torch.from_numpy(fields.smooth_field(B, H, W, seed + 2, noise=0.01)).requires_grad_(True)
+                    # p as [B,H,W] (what the 'curl' head returns); the 'mae' head's un-squeezed [B,1,H,W] would broadcast
+                    # against the [B,H,W] truth - the build squeezes
+                    p = torch.from_numpy(fields.smooth_field(B, H, W, seed + 3, amp=0.5)).requires_grad_(True)
+                    truth = [fields.smooth_field(B, H, W, seed + 5), fields.smooth_field(B, H, W, seed + 6)]
+                    if p_pred:
+                        truth.append(fields.smooth_field(B, H, W, seed + 7, amp=0.5))
+                    uvp = torch.from_numpy(np.stack(truth, 1))
+                    gVTp = torch.from_numpy(fields.unet_input(B, H, W, seed, c_i=7))
+                    ns = _trainer_ns(_Stub3(u, v, p if p_pred else None), p_pred, loss_scale, loss_derivative, loss_type)
+                    ns.net = "newfluidnet"
+                    out = G.Trainer.get_loss(ns, gVTp, uvp, None, None, None)
+                    out[0].backward()
+                    rows.append([int(p_pred), {"mae": 0, "mass": 1, "curl": 2}[loss_type], int(loss_scale),
+                                 int(loss_derivative), seed] + [float(o) for o in out])
+                    samples[f"du/{case}"] = fields.strided_sample(u.grad.numpy())
+                    samples[f"dv/{case}"] = fields.strided_sample(v.grad.numpy())
+                    if p_pred:
+                        samples[f"dp/{case}"] = fields.strided_sample(p.grad.numpy())
+                    case += 1
+    npz("g13_get_loss_fluidnet", table=np.array(rows), **samples)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()
