@@ -20,7 +20,7 @@ OUT_NAMES = ("loss", "loss_true_u", "loss_true_v", "loss_p", "loss_T", "mass", "
 class StokesLoss:
     def __init__(self, p_pred: bool, loss_type: str, loss_scale: bool = False, loss_derivative: bool = False,
                  norm: str = "l1", lambda_mom: float = 0.0, inv_h: float = 126.0, ra: float = 1.0,
-                 a_bound: float = 10.0, t_grad: bool = True):
+                 a_bound: float = 10.0, t_grad: bool = True, has_T: bool = True):
         if loss_type not in L.LOSS_TYPES:
             raise ValueError(f"loss_type must be one of {list(L.LOSS_TYPES)}")
         if norm not in ("l1", "l2"):
@@ -29,6 +29,11 @@ class StokesLoss:
         self.loss_scale, self.loss_derivative = bool(loss_scale), bool(loss_derivative)
         self.norm, self.lambda_mom, self.inv_h, self.ra = norm, float(lambda_mom), float(inv_h), float(ra)
         self.a_bound, self.t_grad = float(a_bound), bool(t_grad)
+        # has_T = False: FluidNet family (reference get_loss, multigpu.py:138-195): outputs (u, v[, p]) / (streamfunction[, p]),
+        # truth (u, v[, p]), no temperature term, scaled pressure loss
+        self.has_T = bool(has_T)
+        if not self.has_T and self.lambda_mom != 0.0:
+            raise ValueError("the momentum residual needs the temperature output (Unet); use lambda_mom = 0 with has_T = False")
         self._shape = None
 
     # ------------------------------------------------------------------
@@ -51,9 +56,10 @@ class StokesLoss:
         self._shape = (N, Cc, H, W, str(dev))
 
     def channels_needed(self):
+        t = 1 if self.has_T else 0
         if self.loss_type == "curl":
-            return 3 if self.p_pred else 2
-        return 4 if self.p_pred else 3
+            return 1 + t + (1 if self.p_pred else 0)
+        return 2 + t + (1 if self.p_pred else 0)
 
     def evaluate(self, y: torch.Tensor, uvp: torch.Tensor, yc: Optional[torch.Tensor] = None,
                  paras: Optional[torch.Tensor] = None, scaler: Optional[torch.Tensor] = None):
@@ -69,7 +75,7 @@ class StokesLoss:
         N, Cc, H, W = y.shape
         if Cc < self.channels_needed():
             raise ValueError(f"network output has {Cc} channels, loss needs {self.channels_needed()}")
-        ct = 4 if self.p_pred else 3
+        ct = (3 if self.p_pred else 2) + (1 if self.has_T else 0)
         if tuple(uvp.shape) != (N, ct, H, W):
             raise ValueError(f"uvp must be [{N},{ct},{H},{W}], got {tuple(uvp.shape)}")
         self._alloc(N, Cc, H, W, y.device)
@@ -77,12 +83,21 @@ class StokesLoss:
         HW = H * W
         d = L.LossDesc(N, H, W, int(self.p_pred), L.LOSS_TYPES[self.loss_type], int(self.loss_scale),
                        int(self.loss_derivative), int(self.norm == "l2"), self.lambda_mom, self.inv_h, self.ra,
-                       int(self.t_grad))
+                       int(self.t_grad) if self.has_T else -1)
         self.sums.zero_()
         if self.loss_scale:
             L.call("mc_loss_minmax", L.ptr(uvp), N, ct, H, W, L.ptr(self.mm), st)
         yb, gb = y.data_ptr(), self.gy.data_ptr()
-        if self.loss_type == "curl":
+        if self.loss_type == "curl" and not self.has_T:
+            # NewFluidNet: channel 0 = streamfunction, 1 = p  (reference pytorch_networks_convae.py:1360-1369)
+            self.gy.zero_()
+            L.call("mc_curl_head_fwd", yb, None, N, H, W, Cc * HW, self.a_bound, 0.0, 0.0, L.ptr(self.cu), L.ptr(self.cv),
+                   None, st)
+            u, v, T, pbs = self.cu.data_ptr(), self.cv.data_ptr(), None, HW
+            gu, gv, gT = self.gcu.data_ptr(), self.gcv.data_ptr(), None
+            p = yb + 4 * 1 * HW if self.p_pred else None
+            gp = gb + 4 * 1 * HW if self.p_pred else None
+        elif self.loss_type == "curl":
             # channel 0 = streamfunction, 1 = T, 2 = p  (reference pytorch_networks_convae.py:2038-2049)
             self.gy.zero_()
             L.call("mc_curl_head_fwd", yb, yb + 4 * HW, N, H, W, Cc * HW, self.a_bound, 0.0, 1.5, L.ptr(self.cu),
@@ -91,6 +106,14 @@ class StokesLoss:
             gu, gv, gT = self.gcu.data_ptr(), self.gcv.data_ptr(), self.gcT.data_ptr()
             p = yb + 4 * 2 * HW if self.p_pred else None
             gp = gb + 4 * 2 * HW if self.p_pred else None
+        elif not self.has_T:
+            # NewFluidNet 'mae' / 'mass': channels u, v, p  (:1348-1358)
+            u, v, T, pbs = yb, yb + 4 * HW, None, Cc * HW
+            gu, gv, gT = gb, gb + 4 * HW, None
+            p = yb + 4 * 2 * HW if self.p_pred else None
+            gp = gb + 4 * 2 * HW if self.p_pred else None
+            if Cc > ct:
+                self.gy.zero_()
         else:
             # channels u, v, T, p  (:2026-2036)
             u, v, T, pbs = yb, yb + 4 * HW, yb + 4 * 2 * HW, Cc * HW
@@ -112,7 +135,10 @@ class StokesLoss:
                    L.ptr(self.sums), L.ptr(self.sx), L.ptr(self.sy), L.ptr(self.eta), st)
             L.call("mc_momentum_adjoint", C.byref(d), T, pbs, ppbs, L.ptr(self.eta), L.ptr(paras), L.ptr(scaler),
                    L.ptr(self.sx), L.ptr(self.sy), gu, gv, gp, gT, st)
-        if self.loss_type == "curl":
+        if self.loss_type == "curl" and not self.has_T:
+            L.call("mc_curl_head_bwd", gu, gv, None, None, N, H, W, self.a_bound, 0.0, 0.0, gb, None, Cc * HW, Cc * HW,
+                   L.ptr(self.curl_ws), st)
+        elif self.loss_type == "curl":
             L.call("mc_curl_head_bwd", gu, gv, gT, yb + 4 * HW, N, H, W, self.a_bound, 0.0, 1.5, gb, gb + 4 * HW,
                    Cc * HW, Cc * HW, L.ptr(self.curl_ws), st)
         L.call("mc_loss_finalize", C.byref(d), L.ptr(self.sums), L.ptr(self.out8), st)

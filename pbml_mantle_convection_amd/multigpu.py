@@ -29,7 +29,7 @@ from . import _lib as L
 from .datasetio import *  # noqa: F401,F403  (reference does the same star import)
 from .hipnet import FlatParams
 from .losses import StokesLoss
-from .pytorch_networks_convae import ConvAE, Unet, count_parameters
+from .pytorch_networks_convae import ConvAE, NewFluidNet, Unet, count_parameters
 
 
 def ddp_setup(rank, world_size, master_port, backend: Optional[str] = None):
@@ -81,9 +81,12 @@ class Trainer:
                  optimizer: torch.optim.Optimizer, scheduler, gpu_id: int, save_every: int, nn_dir, p_pred=False,
                  debug=False, network="fluidnet", loss_scale=False, loss_derivative=False, roll_forward=1, epoch=0,
                  loss_type="curl", *, norm="l1", lambda_mom=0.0, precision=None, use_graph=False, log_every=100):
-        if network not in ("unet", "iunet", "convae"):
-            raise NotImplementedError(f"network={network!r}: the HIP hot path covers 'unet' and 'convae' "
-                                      "(FluidNet/NewFluidNet are listed as next rows in SURVEY.md §8f)")
+        if network not in ("unet", "iunet", "convae", "newfluidnet"):
+            raise NotImplementedError(f"network={network!r}: the HIP path covers 'unet', 'convae' and 'newfluidnet' "
+                                      "(SURVEY.md §8f row N1; the older FluidNet trunk is not built)")
+        fluid = "fluidnet" in network          # the reference's `"fluidnet" in self.net` branch of get_loss (:138)
+        if fluid and lambda_mom != 0.0:
+            raise NotImplementedError("the momentum residual needs the temperature output of the Unet")
         if model_AD is not None:
             raise NotImplementedError("model_AD (advection net) is out of scope of the training hot path")
         if roll_forward != 1:
@@ -113,9 +116,9 @@ class Trainer:
         a_bound = getattr(self.model_uvp, "a_bound", 10.0)
         self.loss = StokesLoss(p_pred if network != "convae" else False,
                                loss_type if network != "convae" else "mae", loss_scale, loss_derivative, norm=norm,
-                               lambda_mom=lambda_mom, a_bound=a_bound)
-        if network == "convae":
-            self.chan_scale = None
+                               lambda_mom=lambda_mom, a_bound=a_bound, has_T=not fluid)
+        if network == "convae" or fluid:
+            self.chan_scale = None                    # these nets see gVTp as it is (reference :139)
         else:
             cs = torch.ones(self.model_uvp._graph.c_in, dtype=torch.float32)
             cs[0] = 0.25
@@ -344,7 +347,11 @@ def build_model(network, levels, c_i, c_h, c_o, rank, act_fn, r_p, loss_type, us
         return ConvAE(levels, c_i, c_h, c_o, dev, act_fn, r_p, loss_type, use_symm=use_symm, dilation=dilation,
                       a_bound=a_bound, repeats=repeats, use_skip=use_skip, f=kernel, p_pred=p_pred,
                       spectral_conv=spectral_conv, blurr=blurr)
-    raise NotImplementedError(f"network={network!r} is outside the HIP hot path (unet, convae)")
+    if network == "newfluidnet":
+        return NewFluidNet(levels, c_i, c_h, c_o, dev, act_fn, r_p, loss_type, use_symm=use_symm, dilation=dilation,
+                           a_bound=a_bound, repeats=repeats, use_skip=use_skip, f=kernel, p_pred=p_pred,
+                           spectral_conv=spectral_conv, blurr=blurr, drop_rate=dropout)
+    raise NotImplementedError(f"network={network!r} is outside the HIP path (unet, convae, newfluidnet)")
 
 
 def parse_restart_log(nn_dir, milestones):

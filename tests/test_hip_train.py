@@ -225,3 +225,66 @@ def test_graph_step_in_place_input_buffers():
         res.append((out.clone(), torch.cat([p.detach().flatten() for p in m.parameters()]).clone()))
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
+
+
+# ---------------------------------------------------------------------------------------------- NewFluidNet
+@pytest.mark.parametrize("p_pred", [True, False])
+@pytest.mark.parametrize("loss_type", ["mae", "mass", "curl"])
+@pytest.mark.parametrize("ls,ld", [(False, False), (True, True)])
+def test_fused_loss_fluidnet_mode_matches_oracle(p_pred, loss_type, ls, ld):
+    """has_T = False: the FluidNet branch of get_loss (no temperature term, scaled pressure loss, curl head without T)."""
+    from pbml_mantle_convection_amd.losses import StokesLoss
+    B, H, W = 2, 37, 53
+    u, v, p, _, uvp4 = _case(B, H, W, 300, p_pred)
+    uvp = uvp4[:, :-1]                                                  # truth without the temperature channel
+    a_bound = 4.0
+    if loss_type == "curl":
+        psi = fields.smooth_field(B, H, W, 311, noise=0.01)
+        chans = [psi] + ([p] if p_pred else [])
+    else:
+        chans = [u, v] + ([p] if p_pred else [])
+    y = dev(np.stack(chans, 1))
+    Ls = StokesLoss(p_pred, loss_type, ls, ld, a_bound=a_bound, has_T=False)
+    out8, gy = Ls.evaluate(y, dev(uvp))
+    ty = torch.from_numpy(np.stack(chans, 1)).to(f64).requires_grad_(True)
+    if loss_type == "curl":
+        cu, cv = O.curl_head(ty[:, 0:1] * a_bound)
+        pred = (cu[:, 0], cv[:, 0], ty[:, 1] if p_pred else None)
+    else:
+        pred = (ty[:, 0], ty[:, 1], ty[:, 2] if p_pred else None)
+    ref = O.get_loss_fluidnet(pred, torch.from_numpy(uvp).to(f64), p_pred=p_pred, loss_type=loss_type, loss_scale=ls,
+                              loss_derivative=ld)
+    close(out8[:6], torch.stack([r.detach() for r in ref]), atol=1e-6, rtol=2e-5, what="loss6")
+    ref[0].backward()
+    close(gy, ty.grad, atol=2e-8, rtol=2e-4, what="grad")       # (f32 sums of the curl adjoint: 1e-7 of the largest entry)
+
+
+def test_newfluidnet_training_step_vs_oracle():
+    """One fused training step of a small NewFluidNet (Trainer, network='newfluidnet') against the same step on the CPU
+    oracle: loss tuple and updated weights."""
+    from pbml_mantle_convection_amd.multigpu import Trainer, build_model
+    torch.manual_seed(4)
+    cfg = dict(levels=3, repeats=2, act="gelu", r_p="zeros", loss_type="mass", use_symm=True, p_pred=True)
+    m = build_model("newfluidnet", 3, 7, 8, 3, torch.device("cpu"), "gelu", "zeros", "mass", True, 2, 5, p_pred=True)
+    sd = {k: v.detach().clone().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    B, H, W = 2, 64, 90
+    x = torch.from_numpy(fields.unet_input(B, H, W, 401, c_i=7)).float()
+    uvp = torch.from_numpy(np.stack([fields.smooth_field(B, H, W, 402), fields.smooth_field(B, H, W, 403),
+                                     fields.smooth_field(B, H, W, 404, amp=0.5)], 1)).float()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="newfluidnet",
+                 loss_scale=True, loss_derivative=False, loss_type="mass", precision="fp32")
+    out8 = tr.train_step(x.to(DEV), uvp.to(DEV))
+    # the same step on the CPU oracle
+    ropt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    pred = O.newfluidnet_forward(sd, x.double(), levels=3, repeats=2, act="gelu", r_p="zeros", loss_type="mass",
+                                 use_symm=True, p_pred=True)
+    ref = O.get_loss_fluidnet((pred[0], pred[1], pred[2]), uvp.double(), p_pred=True, loss_type="mass", loss_scale=True)
+    ref[0].backward()
+    ropt.step()
+    close(out8[:6], torch.stack([r.detach() for r in ref]), atol=1e-6, rtol=5e-5, what="loss6")
+    for n, p in m.named_parameters():
+        if n == "conv.3.bias":
+            continue                                                    # null direction (see test_two_training_steps_golden)
+        close(p, sd[n].detach(), atol=1e-4, rtol=1e-4, what="param " + n)
