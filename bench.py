@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    p.add_argument("--workload", type=str, default="cfg3", choices=["cfg3", "newfluidnet"],
+                   help="cfg3 = the headline benchmark; newfluidnet = SURVEY 8(f) N1, the deployed multi-resolution trunk "
+                        "(-net newfluidnet -l 5 -f 16 -r 6 -k 5) on its 128 x 506 grid")
     return p.parse_args()
 
 
@@ -128,19 +131,30 @@ def main():
 
     H, W = args.size
     B = args.batch
+    n1 = args.workload == "newfluidnet"
+    if n1:
+        H, W = 128, 506
+        args.no_cpu_baseline = True                      # (the CPU baseline leg is the headline workload's)
     steps = args.steps if args.steps is not None else (20 if args.precision == "bf16" else 3)
     warmup = args.warmup if args.warmup is not None else (5 if args.precision == "bf16" else 1)
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = Unet(CFG["levels"], CFG["c_i"], CFG["c_h"], CFG["c_o"], dev, CFG["act"], CFG["r_p"], CFG["loss_type"],
-                 use_symm=CFG["use_symm"], repeats=CFG["repeats"], f=CFG["f"], p_pred=CFG["p_pred"])
+    if n1:
+        from pbml_mantle_convection_amd.pytorch_networks_convae import NewFluidNet
+        model = NewFluidNet(5, 7, 16, 3, dev, "gelu", "zeros", "mass", use_symm=True, repeats=6, f=5, p_pred=True)
+    else:
+        model = Unet(CFG["levels"], CFG["c_i"], CFG["c_h"], CFG["c_o"], dev, CFG["act"], CFG["r_p"], CFG["loss_type"],
+                     use_symm=CFG["use_symm"], repeats=CFG["repeats"], f=CFG["f"], p_pred=CFG["p_pred"])
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10 ** 9], gamma=0.5)
-    tr = Trainer(model, None, None, None, None, None, opt, sch, local_rank % ndev, 1, "/tmp/", p_pred=True, network="unet",
-                 loss_scale=False, loss_derivative=False, loss_type=CFG["loss_type"], lambda_mom=args.lambda_mom,
-                 precision=args.precision, use_graph=not args.no_graph)
+    tr = Trainer(model, None, None, None, None, None, opt, sch, local_rank % ndev, 1, "/tmp/", p_pred=True,
+                 network="newfluidnet" if n1 else "unet", loss_scale=n1, loss_derivative=False,
+                 loss_type=CFG["loss_type"], lambda_mom=0.0 if n1 else args.lambda_mom, precision=args.precision,
+                 use_graph=not args.no_graph)
     # synthetic fields, resident in HBM before the timed region (seed differs per rank: independent shards)
     gVTp, uvp, scaler, paras, yc = synthetic_batch(B, H, W, 1234 + rank, p_pred=True, device="cpu")
+    if n1:
+        gVTp, uvp = gVTp[:, :7].contiguous(), uvp[:, :3].contiguous()      # NewADDataset items: x [7,H,W], y (u, v, p)
     gVTp, uvp, scaler, paras, yc = (t.to(dev) for t in (gVTp, uvp, scaler, paras, yc))
 
     def sync():
@@ -186,11 +200,15 @@ def main():
     if rank == 0:
         sps = world * B * steps / elapsed
         line = {
-            "metric": "training samples/sec (2-D 506x506 Stokes fields)", "value": sps, "unit": "samples/s",
+            "metric": "training samples/sec (2-D 128x506 Stokes fields, NewFluidNet)" if n1 else
+                      "training samples/sec (2-D 506x506 Stokes fields)", "value": sps, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"CFG-3: symmetric U-Net (levels 5, c_h 16, k 5, repeats 3, reflect) + L1 data loss "
+            "config": {"workload": (f"N1: NewFluidNet (levels 5, c_h 16, k 5, repeats 6, zeros, symmetric) + scaled L1 data loss "
+                                    f"+ divergence, {H}x{W}, per-GPU batch {B}, Adam, "
+                                    f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}") if n1 else
+                                   f"CFG-3: symmetric U-Net (levels 5, c_h 16, k 5, repeats 3, reflect) + L1 data loss "
                                    f"+ divergence + Stokes momentum residual, {H}x{W}, per-GPU batch {B}, Adam, "
                                    f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}",
                        "global_batch": world * B, "grid": [H, W], "parallelism": f"dp{world}",

@@ -218,3 +218,36 @@ def test_input_gradient_kernel_direct(dtype_name, ci0, ci1, co, k, h, hw):
     assert got.shape == ref.shape
     tol = 1e-2 if dtype_name == "bf16" else 1e-5
     assert float((got - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("tag", ["mae_zeros", "curl_rep"])
+def test_newfluidnet_bf16_vs_golden(golden, tag):
+    """SURVEY 8(f) N1 in bf16 mode: outputs within the bf16 noise floor of the fp64 reference, gradient direction intact."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import NewFluidNet
+    g = golden(f"g12_newfluidnet_{tag}")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm = [int(v) for v in g["cfg"]]
+    m = NewFluidNet(levels, c_i, c_h, c_o, torch.device(DEV), str(g["act"]), str(g["r_p"]), str(g["loss_type"]),
+                    use_symm=bool(symm), repeats=repeats, f=f, p_pred=bool(p_pred))
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]).float() for k in g.files if k.startswith("sd/")})
+    m = m.to(DEV).set_precision("bf16")
+    x = fields.unet_input(1, 128, 506, 121, c_i=c_i)
+    outs = m(dev(x))
+    loss = 0.0
+    for n, o in zip("uvp", outs):
+        ref = g["out/" + n]
+        if not (str(g["loss_type"]) == "curl" and n in "uv"):
+            # (u, v of the curl head are one-pixel differences of the streamfunction: they amplify the white bf16 noise,
+            # DESIGN.md section 4; the streamfunction itself is checked below)
+            assert float(np.abs(o.detach().double().cpu().numpy() - ref).mean()) <= 0.12 * float(np.abs(ref).mean()), n
+        loss = loss + (o * dev(g["ct/" + n])).sum()
+    sd = {k[3:]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith("sd/")}
+    feat = O.newfluidnet_features(sd, torch.from_numpy(x), levels=levels, repeats=repeats, act=str(g["act"]),
+                                  r_p=str(g["r_p"]), use_symm=bool(symm))
+    loss.backward()
+    assert rel_l2(m.features(dev(x)), feat) < 0.12                 # (a second forward: after the backward of the first)
+    num = sum(float((p.grad.double().cpu() - torch.from_numpy(g["grad/" + n])).norm() ** 2) for n, p in m.named_parameters())
+    den = sum(float(np.linalg.norm(g["grad/" + n]) ** 2) for n, _ in m.named_parameters())
+    # white-noise cotangents pushed through the curl adjoint weight exactly the high-frequency content that bf16 storage
+    # noise dominates (tools/diag_newfluidnet.py: fp32 mode 1e-5, bf16 mode 0.2-0.7 per parameter on this random SELU net):
+    # for the 'curl' case only the direction of the concatenated gradient is asserted
+    assert (num / den) ** 0.5 < (0.6 if str(g["loss_type"]) == "curl" else 0.2), (num / den) ** 0.5
