@@ -196,6 +196,13 @@ int mc_bicubic_bwd(const mc_grad_src* g, int32_t n, int32_t c, int32_t hi, int32
                    const int32_t* ty_start, const int32_t* ty_j, const float* ty_w,
                    const int32_t* tx_start, const int32_t* tx_j, const float* tx_w,
                    int32_t dtype, void* dx, void* stream);
+/* The same adjoint as two 1-D passes through an f32 workspace [n][ceil(c/8)][hi][wo][8]: for large scale factors
+ * (NewFluidNet upsamples x4 ... x16 to the full grid, pytorch_networks_convae.py:1239-1244), where a pixel's tap lists
+ * are too long for the tiled kernel. */
+int mc_bicubic_bwd_separable(const mc_grad_src* g, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                             const int32_t* ty_start, const int32_t* ty_j, const float* ty_w,
+                             const int32_t* tx_start, const int32_t* tx_j, const float* tx_w,
+                             int32_t dtype, float* ws, void* dx, void* stream);
 
 /* ---- curl head (Unet :2038-2070): a*a_bound -> u = da/dy, v = -da/dx, antisymmetric walls;
  *      optional T = clip(t_in, t_lo, t_hi) (:2040).  Planes are [h][w] f32 with a batch stride. --- */

@@ -747,6 +747,44 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
   V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
 }
 
+// adjoint of the bicubic upsample for LARGE scale factors (NewFluidNet: x4, x8, x16), where the tile window of the kernel
+// above does not fit and its per-pixel fallback gathers taps_y x taps_x (up to 64 x 64) vectors: two 1-D passes through an
+// f32 intermediate [n][c8][hi][wo][8] instead (taps_y + taps_x per pixel, coalesced along x).
+template <typename T>
+__global__ void k_bicubic_bwd_ypass(mc_grad_src g, int C8, int Hi, int Wo, const int* __restrict__ tys,
+                                    const int* __restrict__ tyj, const float* __restrict__ tyw, float* __restrict__ tmp) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wo; i += gridDim.x * blockDim.x) {
+    const int yi = i / Wo, xo = i - yi * Wo;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = tys[yi]; a < tys[yi + 1]; ++a) {
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      grad_fetch_add<T>(g, n, cb, tyj[a], xo, C8, v);
+      const float w = tyw[a];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+    }
+    V8<float>::st(tmp + cb8_index(n, cb, yi, xo, C8, Hi, Wo), acc);
+  }
+}
+template <typename T>
+__global__ void k_bicubic_bwd_xpass(const float* __restrict__ tmp, int C8, int Hi, int Wi, int Wo, const int* __restrict__ txs,
+                                    const int* __restrict__ txj, const float* __restrict__ txw, T* __restrict__ dx) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wi; i += gridDim.x * blockDim.x) {
+    const int yi = i / Wi, xi = i - yi * Wi;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = txs[xi]; b < txs[xi + 1]; ++b) {
+      float v[8];
+      V8<float>::ld(tmp + cb8_index(n, cb, yi, txj[b], C8, Hi, Wo), v);
+      const float w = txw[b];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+    }
+    V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
+  }
+}
+
 // =================================================================================================
 // torch.cat along channels of more than two operands; sum of two gradient sources
 // =================================================================================================
@@ -1192,6 +1230,27 @@ int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int3
   if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_bwd<float>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (float*)dx, tiles_x);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_bwd<bf16_t>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (bf16_t*)dx, tiles_x);
   else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_bicubic_bwd_separable(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                             const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
+                             const float* txw, int32_t dtype, float* ws, void* dx, void* stream) {
+  if (!gs || !dx || !ws || !tys || !tyj || !tyw || !txs || !txj || !txw || n <= 0 || c <= 0) return MC_EINVAL;
+  int rc = check_gsrc(gs);
+  if (rc) return rc;
+  if (gs->hs != ho || gs->ws != wo || gs->kind == MC_GSRC_NONE) return MC_EINVAL;
+  const int C8 = (c + 7) / 8;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g1(max(1, min(cdiv(hi * wo, 256), 2048)), C8, n), g2(max(1, min(cdiv(hi * wi, 256), 2048)), C8, n);
+  if (dtype == MC_F32) {
+    hipLaunchKernelGGL(k_bicubic_bwd_ypass<float>, g1, dim3(256), 0, s, *gs, C8, hi, wo, tys, tyj, tyw, ws);
+    hipLaunchKernelGGL(k_bicubic_bwd_xpass<float>, g2, dim3(256), 0, s, ws, C8, hi, wi, wo, txs, txj, txw, (float*)dx);
+  } else if (dtype == MC_BF16) {
+    hipLaunchKernelGGL(k_bicubic_bwd_ypass<bf16_t>, g1, dim3(256), 0, s, *gs, C8, hi, wo, tys, tyj, tyw, ws);
+    hipLaunchKernelGGL(k_bicubic_bwd_xpass<bf16_t>, g2, dim3(256), 0, s, ws, C8, hi, wi, wo, txs, txj, txw, (bf16_t*)dx);
+  } else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -369,7 +369,12 @@ class Engine:
                 o.H, o.W = ho, wo
                 o.buf = cb8(o.C, ho, wo)
                 tabs = (self._table(s.H, ho), self._table(s.W, wo))
-                self.plan.append(dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W)))
+                e = dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W))
+                if ho > 3 * s.H or wo > 3 * s.W:
+                    # scale factor > 3: the adjoint runs as two 1-D passes through an f32 workspace (tap lists too long
+                    # for the tiled kernel's window)
+                    e["bws"] = torch.empty((N, (s.C + 7) // 8, s.H, wo, 8), **f32)
+                self.plan.append(e)
                 continue
             if node.kind == "pool":
                 s, o = T[node.src], T[node.out]
@@ -606,8 +611,12 @@ class Engine:
                 s, o = T[node.src], T[node.out]
                 assert len(o.gsrcs) == 1, "an upsampled tensor feeds exactly one conv"
                 (_, _, tys, tyj, tyw), (_, _, txs, txj, txw) = e["tabs"]
-                L.call("mc_bicubic_bwd", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
-                       L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["dsrc"]), st)
+                if "bws" in e:
+                    L.call("mc_bicubic_bwd_separable", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
+                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["bws"]), L.ptr(e["dsrc"]), st)
+                else:
+                    L.call("mc_bicubic_bwd", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
+                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["dsrc"]), st)
                 s.gsrcs.append(L.GradSrc(L.ptr(e["dsrc"]), L.GSRC_PLAIN, 0, 0, 1, s.H, s.W))
                 continue
             d = e["desc"]
