@@ -255,6 +255,17 @@ int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pred_batc
  * (loss, loss_true_u, loss_true_v, loss_p, loss_T, mean mass, mom, 0). */
 int mc_loss_finalize(const mc_loss_desc* d, const double* sums, float* out8, void* stream);
 
+/* ---- on-device batch assembly (ADTimeDataset.__getitem__, datasetio.py:229-280) -----------------
+ * The whole dataset stays resident in HBM: T [m][h][w], uv [m][cy][h][w] (cy >= 2: u, v[, p]), t [m], paras [m][3] =
+ * (RaQ, FKT, FKP), paras_nd [m][3], xc / yc [h][w], all f32.  For every (i0, i1) of pairs [b][2] writes
+ *   x [b][10][h][w] = (xc, yc, t[i1]-t[i0], paras_nd[i0] x3, log10(clip(eta,1e-8,1))/8, T[i0], u[i0]/s, v[i0]/s)
+ *   y [b][3][h][w]  = (u[i1]/s, v[i1]/s, T[i1]),  scaler [b] = s,  paras_out [b][3] = paras[i0]
+ * with s = 5 exp(1.80167667 RaQ/10 + 0.4330392 ln FKT - 0.46052953 ln FKP) (scaler.py:6-13) and
+ * eta = exp(-ln(FKT) T + ln(FKP) (1 - yc)) (pytorch_networks_convae.py:86-102). */
+int mc_assemble_adtime_batch(const float* T, const float* uv, const float* t, const float* paras, const float* paras_nd,
+                             const float* xc, const float* yc, const int32_t* pairs, int32_t b, int32_t m, int32_t cy,
+                             int32_t h, int32_t w, float* x, float* y, float* scaler, float* paras_out, void* stream);
+
 /* ---- optimizer (torch.optim.Adam, multigpu.py:761-763) --------------------------------------- */
 /* One fused multi-tensor step over flat f32 buffers; grad_scale folds the 1/world_size of the
  * data-parallel average; lr is read from device memory so a captured graph can be replayed

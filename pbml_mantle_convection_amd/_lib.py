@@ -80,6 +80,8 @@ SIGNATURES = {
     "mc_curl_head_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "mc_curl_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _i64, _i64,
                                    _vp, _vp]),
+    "mc_assemble_adtime_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
+                                           _vp, _vp, _vp]),
     "mc_loss_minmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_loss_fwd_bwd": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_momentum_residual": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

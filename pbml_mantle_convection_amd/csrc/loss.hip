@@ -289,6 +289,49 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
   }
 }
 
+// on-device batch assembly (ADTimeDataset.__getitem__, datasetio.py:229-280)
+__global__ void k_assemble_adtime(const float* __restrict__ T, const float* __restrict__ uv, const float* __restrict__ t,
+                                  const float* __restrict__ paras, const float* __restrict__ paras_nd,
+                                  const float* __restrict__ xc, const float* __restrict__ yc, const int* __restrict__ pairs,
+                                  int cy, int HW, float* __restrict__ x, float* __restrict__ y, float* __restrict__ scaler,
+                                  float* __restrict__ paras_out) {
+  const int b = blockIdx.y, i0 = pairs[2 * b], i1 = pairs[2 * b + 1];
+  const float raq = paras[i0 * 3], fkt = paras[i0 * 3 + 1], fkp = paras[i0 * 3 + 2];
+  const float lnfkt = logf(fkt), lnfkp = logf(fkp);
+  const float s = 5.0f * expf(raq * 0.1f * 1.80167667f + lnfkt * 0.4330392f + lnfkp * -0.46052953f);
+  const float inv_s = 1.0f / s, dt = t[i1] - t[i0];
+  const float n0 = paras_nd[i0 * 3], n1 = paras_nd[i0 * 3 + 1], n2 = paras_nd[i0 * 3 + 2];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scaler[b] = s;
+    paras_out[b * 3] = raq; paras_out[b * 3 + 1] = fkt; paras_out[b * 3 + 2] = fkp;
+  }
+  const float* T0 = T + (size_t)i0 * HW;
+  const float* T1 = T + (size_t)i1 * HW;
+  const float* u0 = uv + ((size_t)i0 * cy + 0) * HW;
+  const float* v0 = uv + ((size_t)i0 * cy + 1) * HW;
+  const float* u1 = uv + ((size_t)i1 * cy + 0) * HW;
+  const float* v1 = uv + ((size_t)i1 * cy + 1) * HW;
+  float* xb = x + (size_t)b * 10 * HW;
+  float* yb = y + (size_t)b * 3 * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const float Tp = T0[i], ycv = yc[i];
+    const float eta = expf(-lnfkt * Tp + lnfkp * (1.0f - ycv));
+    xb[i] = xc[i];
+    xb[HW + i] = ycv;
+    xb[2 * (size_t)HW + i] = dt;
+    xb[3 * (size_t)HW + i] = n0;
+    xb[4 * (size_t)HW + i] = n1;
+    xb[5 * (size_t)HW + i] = n2;
+    xb[6 * (size_t)HW + i] = log10f(fminf(fmaxf(eta, 1e-8f), 1.0f)) * 0.125f;
+    xb[7 * (size_t)HW + i] = Tp;
+    xb[8 * (size_t)HW + i] = u0[i] * inv_s;
+    xb[9 * (size_t)HW + i] = v0[i] * inv_s;
+    yb[i] = u1[i] * inv_s;
+    yb[HW + i] = v1[i] * inv_s;
+    yb[2 * (size_t)HW + i] = T1[i];
+  }
+}
+
 __global__ void k_loss_finalize(mc_loss_desc d, const double* __restrict__ s, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double N = d.n, H = d.h, W = d.w, NHW = N * H * W;
@@ -381,6 +424,18 @@ int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, int6
   dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
   hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, T, eta_ws, paras, scaler, sx, sy, gu, gv, gp, gT,
                      d->t_grad);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_assemble_adtime_batch(const float* T, const float* uv, const float* t, const float* paras, const float* paras_nd,
+                             const float* xc, const float* yc, const int32_t* pairs, int32_t b, int32_t m, int32_t cy,
+                             int32_t h, int32_t w, float* x, float* y, float* scaler, float* paras_out, void* stream) {
+  if (!T || !uv || !t || !paras || !paras_nd || !xc || !yc || !pairs || !x || !y || !scaler || !paras_out) return MC_EINVAL;
+  if (b <= 0 || m <= 0 || cy < 2 || h <= 0 || w <= 0) return MC_EINVAL;
+  dim3 grid(max(1, min(cdiv(h * w, 256 * 4), 256)), b);
+  hipLaunchKernelGGL(k_assemble_adtime, grid, dim3(256), 0, (hipStream_t)stream, T, uv, t, paras, paras_nd, xc, yc, pairs, cy,
+                     h * w, x, y, scaler, paras_out);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -288,3 +288,40 @@ def test_newfluidnet_training_step_vs_oracle():
         if n == "conv.3.bias":
             continue                                                    # null direction (see test_two_training_steps_golden)
         close(p, sd[n].detach(), atol=1e-4, rtol=1e-4, what="param " + n)
+
+
+def test_resident_dataset_assembles_batches_on_device():
+    """batches built by mc_assemble_adtime_batch from HBM-resident fields equal the host items of
+    ADTimeDataset.__getitem__ (the mirror of datasetio.py:229-280) stacked."""
+    from pbml_mantle_convection_amd.datasetio import ADTimeDataset, ResidentADTimeDataset, normalise_parameters
+    H, W, M = 24, 40, 19
+    ds = ADTimeDataset.__new__(ADTimeDataset)                                   # no files: fill the members synthetically
+    g = torch.Generator().manual_seed(9)
+    ds.x_data = [torch.rand((1, H, W), generator=g, dtype=torch.float64) for _ in range(M)]
+    ds.y_data = [torch.randn((3, H, W), generator=g, dtype=torch.float64) for _ in range(M)]
+    ds.t = [0.01 * i + 0.001 * float(torch.rand(1, generator=g)) for i in range(M)]
+    ds.t_data = [torch.tensor(t, dtype=torch.float64) for t in ds.t]
+    par = [(2.5, 1e7, 30.0), (7.0, 1e9, 3.0)]
+    ds.paras = [torch.tensor(par[i >= 10], dtype=torch.float64).view(3, 1, 1) for i in range(M)]
+    ds.paras_nd = [torch.tensor(normalise_parameters(*par[i >= 10]), dtype=torch.float64).view(3, 1, 1) for i in range(M)]
+    ds.xc = torch.linspace(0, 4, W, dtype=torch.float64).view(1, 1, W).expand(1, H, W).contiguous()
+    ds.yc = torch.linspace(0, 1, H, dtype=torch.float64).view(1, H, 1).expand(1, H, W).contiguous()
+    ds.indices = [[i, i + 1] for i in range(M - 1) if i != 9]
+    ds.indices_init = [[0, 1], [10, 11]]
+    ds.scale, ds.p_pred, ds.noise = True, True, 0.0
+    ds.num_examples = len(ds.indices)
+    rd = ResidentADTimeDataset(ds, DEV)
+    idx = [k for k, (i0, _) in enumerate(ds.indices) if i0 % 8 != 0][:6]         # (i0 % 8 == 0 items are randomised)
+    x, y, sc, pa, yc = rd.assemble(idx)
+    items = [ds[k] for k in idx]
+    close(x, torch.stack([it[0] for it in items]), atol=2e-6, rtol=2e-6, what="x")
+    close(y, torch.stack([it[1] for it in items]), atol=2e-6, rtol=2e-6, what="y")
+    close(sc, torch.stack([it[2].reshape(()) for it in items]), atol=0, rtol=2e-6, what="scaler")
+    close(pa.reshape(-1, 3), torch.stack([it[3].reshape(3) for it in items]), atol=0, rtol=1e-7, what="paras")
+    close(yc, items[0][4], atol=1e-7, rtol=0, what="yc")
+    # in-place into preallocated buffers (what a training loop hands over: Trainer.input_buffers())
+    out = dict(gVTp=torch.zeros_like(x), uvp=torch.zeros_like(y), scaler=torch.zeros_like(sc), paras=torch.zeros((len(idx), 3), device=DEV))
+    rd.assemble(idx, out=out)
+    assert torch.equal(out["gVTp"], x) and torch.equal(out["uvp"], y)
+    # randomised initial-condition substitution keeps to the init pairs
+    assert all(tuple(p) in [(0, 1), (10, 11)] for p in rd.pairs([k for k, (i0, _) in enumerate(ds.indices) if i0 % 8 == 0]))
