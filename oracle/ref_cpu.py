@@ -648,6 +648,74 @@ def get_loss_fluidnet(pred: Tuple[Tensor, Tensor, Optional[Tensor]], uvp: Tensor
 
 
 # --------------------------------------------------------------------------------------
+# ADNet + TS rollout (pytorch_networks_convae.py:266-568) — SURVEY.md §8(f) row N3
+# --------------------------------------------------------------------------------------
+def adnet_step(inputs: Tensor, dt=None, T_prev: Optional[Tensor] = None, CN_max: float = 0.1):
+    """ADNet.forward (:522-568): one explicit upwind advection-diffusion step of the temperature on a non-uniform grid.
+    inputs [B,6,H,W] = (u, v, T, RaQ/Ra, xc, yc); returns (T_next [B,1,H,W], dt).  Like the reference, the wall
+    coordinates are written into xc / yc first (on a copy here)."""
+    u = inputs[:, 0:1, 1:-1, 1:-1]
+    v = inputs[:, 1:2, 1:-1, 1:-1]
+    if T_prev is None:
+        T_prev = inputs[:, 2:3]
+    raq = inputs[:, 3:4, 1:-1, 1:-1]
+    xc = inputs[:, 4:5].clone()
+    yc = inputs[:, 5:6].clone()
+    xc[:, :, :, 0] = 0.0
+    xc[:, :, :, -1] = 4.0
+    yc[:, :, 0, :] = 0.0
+    yc[:, :, -1, :] = 1.0
+    dx_l = dx_left(xc)[..., 1:-1, :]
+    dx_r = dx_right(xc)[..., 1:-1, :]
+    dy_t = dy_top(yc)[..., 1:-1]
+    dy_b = dy_bot(yc)[..., 1:-1]
+    dT_l = dx_left(T_prev)[..., 1:-1, :]
+    dT_r = dx_right(T_prev)[..., 1:-1, :]
+    dT_t = dy_top(T_prev)[..., 1:-1]
+    dT_b = dy_bot(T_prev)[..., 1:-1]
+    dT_dx = (dT_l / dx_l) * (u > 0) + (dT_r / dx_r) * (u < 0)
+    dT_dy = (dT_t / dy_t) * (v > 0) + (dT_b / dy_b) * (v < 0)
+    lap = (dT_r / dx_r - dT_l / dx_l) / (0.5 * dx_r + 0.5 * dx_l) + (dT_b / dy_b - dT_t / dy_t) / (0.5 * dy_b + 0.5 * dy_t)
+    if dt is None:
+        dx_min = torch.amin(dx_l)
+        uv_mag = torch.max(torch.amax(torch.abs(u)), torch.amax(torch.abs(v)))
+        dt = torch.min(0.5 * CN_max * dx_min / uv_mag, 0.5 * ((dx_min * dx_min) ** 2) / (dx_min ** 2 + dx_min ** 2))
+    Tn = T_prev[..., 1:-1, 1:-1] + dt * (-u * dT_dx - v * dT_dy + lap + raq)
+    Tn = F.pad(Tn, (1, 1, 1, 1), mode="replicate")
+    Tn[:, :, 0, :] = 1.0
+    Tn[:, :, -1, :] = 0.0
+    return Tn, dt
+
+
+def ts_rollout(stokes, T_prev, ycc, raq_nd, fkt_nd, fkp_nd, raq, fkt, fkp, xc, yc, ts: int, CN_max: float = 0.1):
+    """TS.forward, 'newfluidnet' branch with an advection net (:354-476): ts times { build the 7-channel input
+    (xc/4, yc/4, log10(clip(eta))/8, the three normalised parameters, T) -> stokes -> un-scale u, v -> ADNet step ->
+    wall / side boundary conditions }.  `stokes(inp)` returns (u, v, p) (any shapes reshapeable to [B,1,H,W]).
+    Returns (x dict, dts dict, u, v, p, V) like the reference."""
+    B, _, H, W = T_prev.shape
+    x, dts = {0: T_prev}, {}
+    u = v = p = V = None
+    for i in range(1, ts + 1):
+        V = torch.clip(eta_torch(fkt, fkp, 1.0 - ycc, x[i - 1]), 1e-8, 1.0)
+        inp = torch.cat((xc / 4.0, yc / 4.0, torch.log10(V) / 8, raq_nd.expand(1, 1, H, W), fkt_nd.expand(1, 1, H, W),
+                         fkp_nd.expand(1, 1, H, W), x[i - 1]), dim=1)
+        u, v, p = stokes(inp)
+        sc = torch.exp((raq / 10) * 1.80167667 + torch.log(fkt) * 0.4330392 + torch.log(fkp) * -0.46052953) * 5
+        u = (u * sc).reshape(-1, 1, H, W)
+        v = (v * sc).reshape(-1, 1, H, W)
+        if p is not None:
+            p = p.reshape(-1, 1, H, W)
+        ad_in = torch.cat((u, v, x[i - 1], torch.zeros_like(u) + raq, xc, yc), dim=1)
+        Tn, dt = adnet_step(ad_in, CN_max=CN_max)
+        Tn[:, :, 0, :] = 1
+        Tn[:, :, -1, :] = 0
+        Tn[:, :, :, 0:1] = Tn[:, :, :, 1:2]
+        Tn[:, :, :, -1:] = Tn[:, :, :, -2:-1]
+        x[i], dts[i] = Tn, dt
+    return x, dts, u, v, p, V
+
+
+# --------------------------------------------------------------------------------------
 # Stokes momentum residual — BUILD-DEFINED (SURVEY.md row A12; no reference implementation)
 # --------------------------------------------------------------------------------------
 INV_H = 126.0   # 1/h, grid of 126 layers (prepare_gaia_ini.py:22-27; multigpu.py:163-166 uses x126)

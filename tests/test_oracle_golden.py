@@ -356,3 +356,58 @@ def test_bf16_mode_gelu_polynomials_are_within_bf16_rounding():
     # exact at the origin, monotone saturation outside the fitted interval
     assert float(O.gelu_bf16_mode(torch.zeros(1))) == 0.0
     assert float(O.gelu_grad_bf16_mode(torch.zeros(1))) == 0.5
+
+
+def _n3_grid(H, W):
+    xs = np.concatenate(([0.0], (np.arange(W - 2) + 0.5) * 4.0 / (W - 2), [4.0]))
+    ys = np.concatenate(([0.0], (np.arange(H - 2) + 0.5) * 1.0 / (H - 2), [1.0]))
+    xc = torch.from_numpy(np.broadcast_to(xs[None, :], (H, W)).copy()).view(1, 1, H, W)
+    yc = torch.from_numpy(np.broadcast_to(ys[:, None], (H, W)).copy()).view(1, 1, H, W)
+    return xc, yc
+
+
+def _stokes_stub(inp):
+    """the deterministic stand-in used by tools/make_golden.py g15"""
+    import torch.nn.functional as F
+    Tt = inp[:, 6:7]
+    a = torch.cumsum(Tt - Tt.mean(), dim=3) * 0.01
+    u = F.pad((a[:, :, 2:, 1:-1] - a[:, :, :-2, 1:-1]) * 0.5, (1, 1, 1, 1))
+    v = F.pad(-(a[:, :, 1:-1, 2:] - a[:, :, 1:-1, :-2]) * 0.5, (1, 1, 1, 1))
+    return u[:, 0], v[:, 0], Tt[:, 0] * 0.0
+
+
+def test_adnet_step(golden):
+    """the explicit upwind advection-diffusion step (ADNet.forward) incl. its CFL time step."""
+    g = golden("g14_adnet")
+    H, W = 128, 506
+    xc, yc = _n3_grid(H, W)
+    for k, seed in enumerate(g["seeds"]):
+        seed = int(seed)
+        u = T(fields.smooth_field(1, H, W, seed + 1)).view(1, 1, H, W) * 400.0
+        v = T(fields.smooth_field(1, H, W, seed + 2)).view(1, 1, H, W) * 400.0
+        Tp = T(fields.temperature_field(1, H, W, seed + 3)).view(1, 1, H, W)
+        inp = torch.cat((u, v, Tp, torch.full((1, 1, H, W), 2.5, dtype=torch.float64), xc, yc), dim=1)
+        Tn, dt = O.adnet_step(inp)
+        close(dt, g[f"dt/{k}"], rtol=1e-12)
+        close(Tn if k == 0 else fields.strided_sample(Tn.numpy(), 4001), g[f"T_next/{k}"], atol=1e-12)
+        Tn2, _ = O.adnet_step(inp, dt=torch.tensor(3e-7, dtype=torch.float64))
+        close(fields.strided_sample(Tn2.numpy(), 4001), g[f"T_next_fixed/{k}"], atol=1e-12)
+
+
+def test_ts_rollout(golden):
+    """three steps of TS.forward ('newfluidnet' branch: input builder, un-scaling, ADNet, boundary rows)."""
+    g = golden("g15_ts_rollout")
+    H, W = 128, 506
+    xc, yc = _n3_grid(H, W)
+    T0 = T(fields.temperature_field(1, H, W, 1500)).view(1, 1, H, W)
+    raq, fkt, fkp = (torch.tensor(float(v), dtype=torch.float64) for v in g["paras"])
+    nd = [torch.tensor(float(v), dtype=torch.float64).view(1, 1, 1, 1) for v in g["nd"]]
+    x, dts, u, v, p, V = O.ts_rollout(_stokes_stub, T0, yc, nd[0], nd[1], nd[2], raq, fkt, fkp, xc, yc, ts=3)
+    close(torch.stack([dts[i] for i in (1, 2, 3)]), g["dts"], rtol=1e-10)
+    smp = lambda t: fields.strided_sample(t.numpy(), 4001)  # noqa: E731
+    close(smp(x[1]), g["T1"], atol=1e-11)
+    close(smp(x[2]), g["T2"], atol=1e-11)
+    close(x[3], g["T3"], atol=1e-11)
+    close(smp(u), g["u"], atol=1e-11)
+    close(smp(v), g["v"], atol=1e-11)
+    close(smp(V), g["V"], atol=1e-12)

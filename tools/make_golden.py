@@ -15,6 +15,7 @@ import types
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("MANTLE_REFERENCE", "/root/reference")
@@ -437,10 +438,66 @@ def g13():
     npz("g13_get_loss_fluidnet", table=np.array(rows), **samples)
 
 
+# ------------------------------------------------------------------ G14 ADNet step, G15 TS rollout
+def _grid(H, W):
+    # cell-centred non-uniform-looking grid with wall nodes (datasetio.py:401-404 pattern): interior centres, walls at 0 / 4, 0 / 1
+    xs = np.concatenate(([0.0], (np.arange(W - 2) + 0.5) * 4.0 / (W - 2), [4.0]))
+    ys = np.concatenate(([0.0], (np.arange(H - 2) + 0.5) * 1.0 / (H - 2), [1.0]))
+    xc = torch.from_numpy(np.broadcast_to(xs[None, :], (H, W)).copy()).view(1, 1, H, W)
+    yc = torch.from_numpy(np.broadcast_to(ys[:, None], (H, W)).copy()).view(1, 1, H, W)
+    return xc, yc
+
+
+def g14():
+    H, W = 128, 506
+    ad = P.ADNet(CPU)
+    xc, yc = _grid(H, W)
+    out = {}
+    for k, seed in enumerate((1400, 1410)):
+        u = torch.from_numpy(fields.smooth_field(1, H, W, seed + 1)).view(1, 1, H, W) * 400.0
+        v = torch.from_numpy(fields.smooth_field(1, H, W, seed + 2)).view(1, 1, H, W) * 400.0
+        T = torch.from_numpy(fields.temperature_field(1, H, W, seed + 3)).view(1, 1, H, W)
+        raq = torch.full((1, 1, H, W), 2.5, dtype=f64)
+        inp = torch.cat((u, v, T, raq, xc.clone(), yc.clone()), dim=1)
+        Tn, dt = ad(inp.clone())
+        out[f"T_next/{k}"], out[f"dt/{k}"] = (Tn if k == 0 else fields.strided_sample(Tn.numpy(), 4001)), dt
+        Tn2, dt2 = ad(inp.clone(), dt=torch.tensor(3e-7, dtype=f64))
+        out[f"T_next_fixed/{k}"] = fields.strided_sample(Tn2.numpy(), 4001)
+    npz("g14_adnet", seeds=np.array([1400, 1410]), **out)
+
+
+class _StokesStub(torch.nn.Module):
+    """A deterministic stand-in for the Stokes net: smooth velocities that depend on the temperature input."""
+
+    def forward(self, inp):
+        T = inp[:, 6:7]
+        a = torch.cumsum(T - T.mean(), dim=3) * 0.01
+        u = (a[:, :, 2:, 1:-1] - a[:, :, :-2, 1:-1]) * 0.5
+        v = -(a[:, :, 1:-1, 2:] - a[:, :, 1:-1, :-2]) * 0.5
+        u = F.pad(u, (1, 1, 1, 1))
+        v = F.pad(v, (1, 1, 1, 1))
+        return u[:, 0], v[:, 0], T[:, 0] * 0.0
+
+
+def g15():
+    import torch.nn.functional as F_  # noqa: F401
+    H, W = 128, 506
+    xc, yc = _grid(H, W)
+    T0 = torch.from_numpy(fields.temperature_field(1, H, W, 1500)).view(1, 1, H, W)
+    raq, fkt, fkp = (torch.tensor(v, dtype=f64) for v in (2.5, 1e7, 30.0))
+    nd = [torch.tensor(v, dtype=f64).view(1, 1, 1, 1) for v in (0.25, 0.26, 0.74)]
+    ts = P.TS(_StokesStub(), P.ADNet(CPU), CPU, ts=3, net="newfluidnet")
+    x, dts, u, v, p, V = ts(T0.clone(), None, None, yc.clone(), nd[0], nd[1], nd[2], raq, fkt, fkp, xc.clone(), yc.clone())
+    smp = lambda t: fields.strided_sample(t.numpy(), 4001)  # noqa: E731
+    npz("g15_ts_rollout", T1=smp(x[1]), T2=smp(x[2]), T3=x[3], dts=np.array([float(dts[i]) for i in (1, 2, 3)]), u=smp(u),
+        v=smp(v), V=smp(V),
+        nd=np.array([0.25, 0.26, 0.74]), paras=np.array([2.5, 1e7, 30.0]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()
