@@ -266,6 +266,23 @@ int mc_assemble_adtime_batch(const float* T, const float* uv, const float* t, co
                              const float* xc, const float* yc, const int32_t* pairs, int32_t b, int32_t m, int32_t cy,
                              int32_t h, int32_t w, float* x, float* y, float* scaler, float* paras_out, void* stream);
 
+/* ---- inference rollout (TS.forward / ADNet.forward, pytorch_networks_convae.py:266-568) ----------
+ * Input builder of the 'newfluidnet' branch (:372-395): out [n][7][h][w] = (xc/4, yc/4, log10(clip(eta,1e-8,1))/8, nd0, nd1,
+ * nd2, T) with eta = exp(-ln(FKT) T + ln(FKP) (1 - ycc)); T [n][h][w], xc/yc/ycc [h][w], paras [n][3] = (RaQ, FKT, FKP),
+ * paras_nd [n][3]. */
+int mc_ts_build_input(const float* T, const float* xc, const float* yc, const float* ycc, const float* paras,
+                      const float* paras_nd, int32_t n, int32_t h, int32_t w, float* out, void* stream);
+/* One explicit upwind advection-diffusion step (ADNet.forward :522-568) on the non-uniform grid xc / yc [h][w] (wall
+ * coordinates 0 / 4 and 0 / 1 are substituted on the fly, as the reference writes them into its inputs): u, v [n][h][w]
+ * with batch stride uv_stride, multiplied by vel_scale[n] (NULL = 1: TS un-scales the network's velocities, :397-398);
+ * raq_field [n][h][w] or NULL with raq_scalar[n]; dt_io: device scalar; compute_dt != 0 -> the CFL step
+ * min(0.5 CN_max dx_min / max|u,v|, dx_min^2 / 4) is computed into it first (ws: 2 x uint32 scratch), else it is read.
+ * T_next [n][h][w]: interior updated, replicate-padded, first row 1, last row 0 (side columns = their neighbours, which
+ * is also TS's side condition :466-469). */
+int mc_adnet_step(const float* u, const float* v, int64_t uv_stride, const float* vel_scale, const float* T_prev,
+                  const float* raq_field, const float* raq_scalar, const float* xc, const float* yc, int32_t n, int32_t h,
+                  int32_t w, float cn_max, int32_t compute_dt, float* dt_io, uint32_t* ws, float* T_next, void* stream);
+
 /* ---- optimizer (torch.optim.Adam, multigpu.py:761-763) --------------------------------------- */
 /* One fused multi-tensor step over flat f32 buffers; grad_scale folds the 1/world_size of the
  * data-parallel average; lr is read from device memory so a captured graph can be replayed

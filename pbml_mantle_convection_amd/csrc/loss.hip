@@ -332,6 +332,96 @@ __global__ void k_assemble_adtime(const float* __restrict__ T, const float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// inference rollout: TS input builder and the ADNet step (pytorch_networks_convae.py:372-395, 522-568)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_ts_build_input(const float* __restrict__ T, const float* __restrict__ xc, const float* __restrict__ yc,
+                                 const float* __restrict__ ycc, const float* __restrict__ paras,
+                                 const float* __restrict__ nd, int HW, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float lnfkt = logf(paras[n * 3 + 1]), lnfkp = logf(paras[n * 3 + 2]);
+  const float n0 = nd[n * 3], n1 = nd[n * 3 + 1], n2 = nd[n * 3 + 2];
+  const float* Tn = T + (size_t)n * HW;
+  float* o = out + (size_t)n * 7 * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const float t = Tn[i];
+    const float eta = fminf(fmaxf(expf(-lnfkt * t + lnfkp * (1.0f - ycc[i])), 1e-8f), 1.0f);
+    o[i] = xc[i] * 0.25f;
+    o[HW + i] = yc[i] * 0.25f;
+    o[2 * (size_t)HW + i] = log10f(eta) * 0.125f;
+    o[3 * (size_t)HW + i] = n0;
+    o[4 * (size_t)HW + i] = n1;
+    o[5 * (size_t)HW + i] = n2;
+    o[6 * (size_t)HW + i] = t;
+  }
+}
+
+struct AdGeom { int N, H, W; int64_t uvs; float cn; };
+__device__ __forceinline__ float ad_x(const float* xc, int i, int j, int W) { return j == 0 ? 0.f : (j == W - 1 ? 4.f : xc[(size_t)i * W + j]); }
+__device__ __forceinline__ float ad_y(const float* yc, int i, int j, int H, int W) { return i == 0 ? 0.f : (i == H - 1 ? 1.f : yc[(size_t)i * W + j]); }
+
+// ws[0] = bits of max |u|,|v| over the interior (uint order == float order for non-negative floats), ws[1] = bits of min dx_l
+__global__ void k_adnet_reduce(AdGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
+                               const float* __restrict__ vs, const float* __restrict__ xc, uint32_t* __restrict__ ws) {
+  const int n = blockIdx.y, H = g.H, W = g.W;
+  const float s = vs ? vs[n] : 1.f;
+  const float* u = u_ + (size_t)n * g.uvs;
+  const float* v = v_ + (size_t)n * g.uvs;
+  float mx = 0.f, mn = 3.4e38f;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (H - 2) * (W - 2); idx += gridDim.x * blockDim.x) {
+    const int i = idx / (W - 2) + 1, j = idx % (W - 2) + 1;
+    mx = fmaxf(mx, fmaxf(fabsf(s * u[(size_t)i * W + j]), fabsf(s * v[(size_t)i * W + j])));
+    mn = fminf(mn, ad_x(xc, i, j, W) - ad_x(xc, i, j - 1, W));
+  }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(ws, __float_as_uint(mx));
+    atomicMin(ws + 1, __float_as_uint(mn));
+  }
+}
+__global__ void k_adnet_dt(float cn, const uint32_t* __restrict__ ws, float* __restrict__ dt) {
+  const float uv = __uint_as_float(ws[0]), dx = __uint_as_float(ws[1]);
+  const float dx2 = dx * dx;
+  dt[0] = fminf(0.5f * cn * dx / uv, 0.5f * (dx2 * dx2) / (dx2 + dx2));
+}
+__global__ void k_adnet_ws_init(uint32_t* ws) { ws[0] = 0u; ws[1] = 0x7f7fffffu; }
+
+__global__ __launch_bounds__(256) void k_adnet_step(AdGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
+                                                    const float* __restrict__ vs, const float* __restrict__ T_,
+                                                    const float* __restrict__ rq_, const float* __restrict__ rqs,
+                                                    const float* __restrict__ xc, const float* __restrict__ yc,
+                                                    const float* __restrict__ dtp, float* __restrict__ out_) {
+  const int n = blockIdx.y, H = g.H, W = g.W;
+  const float s = vs ? vs[n] : 1.f, dt = dtp[0];
+  const float* u = u_ + (size_t)n * g.uvs;
+  const float* v = v_ + (size_t)n * g.uvs;
+  const float* T = T_ + (size_t)n * H * W;
+  const float* rq = rq_ ? rq_ + (size_t)n * H * W : nullptr;
+  const float rqc = rqs ? rqs[n] : 0.f;
+  float* out = out_ + (size_t)n * H * W;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
+    const int i = idx / W, j = idx - i * W;
+    float r;
+    if (i == 0) r = 1.0f;
+    else if (i == H - 1) r = 0.0f;
+    else {
+      const int jj = min(max(j, 1), W - 2);                   // side columns replicate their neighbour
+      const size_t c = (size_t)i * W + jj;
+      const float Tc = T[c], uu = s * u[c], vv = s * v[c];
+      const float xm = ad_x(xc, i, jj - 1, W), x0 = ad_x(xc, i, jj, W), xp = ad_x(xc, i, jj + 1, W);
+      const float ym = ad_y(yc, i - 1, jj, H, W), y0 = ad_y(yc, i, jj, H, W), yp = ad_y(yc, i + 1, jj, H, W);
+      const float dxl = x0 - xm, dxr = xp - x0, dyt = y0 - ym, dyb = yp - y0;
+      const float gl = (Tc - T[c - 1]) / dxl, gr = (T[c + 1] - Tc) / dxr;
+      const float gt = (Tc - T[c - W]) / dyt, gb = (T[c + W] - Tc) / dyb;
+      const float dTdx = (uu > 0.f ? gl : 0.f) + (uu < 0.f ? gr : 0.f);
+      const float dTdy = (vv > 0.f ? gt : 0.f) + (vv < 0.f ? gb : 0.f);
+      const float lap = (gr - gl) / (0.5f * dxr + 0.5f * dxl) + (gb - gt) / (0.5f * dyb + 0.5f * dyt);
+      r = Tc + dt * (-uu * dTdx - vv * dTdy + lap + (rq ? rq[c] : rqc));
+    }
+    out[idx] = r;
+  }
+}
+
 __global__ void k_loss_finalize(mc_loss_desc d, const double* __restrict__ s, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double N = d.n, H = d.h, W = d.w, NHW = N * H * W;
@@ -436,6 +526,34 @@ int mc_assemble_adtime_batch(const float* T, const float* uv, const float* t, co
   dim3 grid(max(1, min(cdiv(h * w, 256 * 4), 256)), b);
   hipLaunchKernelGGL(k_assemble_adtime, grid, dim3(256), 0, (hipStream_t)stream, T, uv, t, paras, paras_nd, xc, yc, pairs, cy,
                      h * w, x, y, scaler, paras_out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_ts_build_input(const float* T, const float* xc, const float* yc, const float* ycc, const float* paras,
+                      const float* paras_nd, int32_t n, int32_t h, int32_t w, float* out, void* stream) {
+  if (!T || !xc || !yc || !ycc || !paras || !paras_nd || !out || n <= 0 || h <= 0 || w <= 0) return MC_EINVAL;
+  dim3 grid(max(1, min(cdiv(h * w, 256), 1024)), n);
+  hipLaunchKernelGGL(k_ts_build_input, grid, dim3(256), 0, (hipStream_t)stream, T, xc, yc, ycc, paras, paras_nd, h * w, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_adnet_step(const float* u, const float* v, int64_t uv_stride, const float* vel_scale, const float* T_prev,
+                  const float* raq_field, const float* raq_scalar, const float* xc, const float* yc, int32_t n, int32_t h,
+                  int32_t w, float cn_max, int32_t compute_dt, float* dt_io, uint32_t* ws, float* T_next, void* stream) {
+  if (!u || !v || !T_prev || !xc || !yc || !dt_io || !T_next || n <= 0 || h < 3 || w < 3) return MC_EINVAL;
+  if (!raq_field && !raq_scalar) return MC_EINVAL;
+  if (compute_dt && !ws) return MC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  AdGeom g{n, h, w, uv_stride, cn_max};
+  dim3 grid(max(1, min(cdiv(h * w, 256), 1024)), n);
+  if (compute_dt) {
+    hipLaunchKernelGGL(k_adnet_ws_init, dim3(1), dim3(1), 0, s, ws);
+    hipLaunchKernelGGL(k_adnet_reduce, grid, dim3(256), 0, s, g, u, v, vel_scale, xc, ws);
+    hipLaunchKernelGGL(k_adnet_dt, dim3(1), dim3(1), 0, s, cn_max, ws, dt_io);
+  }
+  hipLaunchKernelGGL(k_adnet_step, grid, dim3(256), 0, s, g, u, v, vel_scale, T_prev, raq_field, raq_scalar, xc, yc, dt_io, T_next);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

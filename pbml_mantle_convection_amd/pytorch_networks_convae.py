@@ -358,6 +358,97 @@ class NewFluidNet(nn.Module, HipNetMixin):
 
 
 # --------------------------------------------------------------------------------------------------
+# ADNet + TS: the inference rollout (reference :266-568) — SURVEY.md §8(f) row N3
+# --------------------------------------------------------------------------------------------------
+class ADNet(nn.Module):
+    """Explicit upwind advection-diffusion step of the temperature field (reference :478-568) as ONE fused HIP stencil
+    kernel (+ a reduction for the CFL time step).  forward(inputs [B,6,H,W] = (u, v, T, RaQ/Ra, xc, yc), dt=None,
+    T_prev=None) -> (T_next [B,1,H,W], dt); the grid channels of sample 0 are used for the whole batch."""
+
+    def __init__(self, device=None, r_p="zeros", CN_max=0.1):
+        super().__init__()
+        self.device, self.CN_max = device, CN_max
+        self._ws = None
+
+    def step(self, u, v, T_prev, xc, yc, *, raq_field=None, raq_scalar=None, vel_scale=None, dt=None, out=None, dt_out=None):
+        """Raw form on device planes (f32, contiguous): u, v [B,H,W] (or a strided view with a batch stride), T_prev [B,H,W],
+        xc / yc [H,W]; returns (T_next [B,H,W], dt device scalar)."""
+        L.require_cuda(T_prev, "T_prev")
+        B, H, W = T_prev.shape[0], T_prev.shape[-2], T_prev.shape[-1]
+        dev = T_prev.device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = torch.zeros(2, dtype=torch.int32, device=dev)
+        out = out if out is not None else torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        dt_dev = dt_out if dt_out is not None else torch.empty(1, dtype=torch.float32, device=dev)
+        if dt is not None:
+            dt_dev.copy_(torch.as_tensor(dt, dtype=torch.float32).reshape(1))
+        uvs = u.stride(0) if u.dim() >= 3 and B > 1 else H * W
+        L.call("mc_adnet_step", L.ptr(u), L.ptr(v), int(uvs), L.ptr(vel_scale), L.ptr(T_prev), L.ptr(raq_field),
+               L.ptr(raq_scalar), L.ptr(xc), L.ptr(yc), B, H, W, float(self.CN_max), int(dt is None), L.ptr(dt_dev),
+               L.ptr(self._ws), L.ptr(out), L.stream())
+        return out, dt_dev
+
+    def forward(self, inputs, dt=None, T_prev=None):
+        inputs = inputs.float().contiguous()
+        L.require_cuda(inputs, "inputs")
+        B, _, H, W = inputs.shape
+        Tp = (T_prev if T_prev is not None else inputs[:, 2]).float().reshape(B, H, W).contiguous()
+        u, v = inputs[:, 0], inputs[:, 1]                      # planes of `inputs`: batch stride 6 H W
+        out, dt_dev = self.step(u, v, Tp, inputs[0, 4].contiguous(), inputs[0, 5].contiguous(),
+                                raq_field=inputs[:, 3].contiguous(), dt=dt)
+        return out.view(B, 1, H, W), (dt_dev[0] if dt is None else dt)
+
+
+class TS(nn.Module):
+    """Evaluation wrapper for time stepping (reference :266-476), 'newfluidnet' branch with an advection net: ts times
+    { input builder -> Stokes net -> un-scale u, v -> ADNet step -> boundary rows / columns }, every stage a HIP kernel on
+    HBM-resident planes (no host round trip inside the loop).  Same constructor and forward signature as the reference;
+    returns (x dict, dts dict, u, v, p, V)."""
+
+    def __init__(self, stokes, ad, device, ts=8, advection_scheme=2, scale=True, p_pred=True, net="fluidnet"):
+        super().__init__()
+        if net not in ("newfluidnet",):
+            raise NotImplementedError("TS on the HIP path covers net='newfluidnet' (the deployed configuration)")
+        if ad is None:
+            raise NotImplementedError("TS needs the advection net (ADNet)")
+        self.stokes, self.ad, self.ts, self.device = stokes, ad, ts, device
+        self.advection_scheme, self.scale, self.p_pred, self.net = advection_scheme, scale, p_pred, net
+
+    @torch.no_grad()
+    def forward(self, T_prev, sdf, sdf2, ycc, raq_nd, fkt_nd, fkp_nd, raq, fkt, fkp, xc, yc, u_prev=None, v_prev=None,
+                dt=None):
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        f = dict(dtype=torch.float32, device=dev)
+        B, _, H, W = T_prev.shape
+        plane = lambda t: torch.as_tensor(t).to(**f).reshape(-1, H, W)[0].contiguous()  # noqa: E731
+        xcp, ycp, yccp = plane(xc), plane(yc), plane(ycc)
+        sc3 = lambda a, b, c: torch.stack([torch.as_tensor(t, dtype=torch.float32).reshape(-1)[:1].expand(B) for t in (a, b, c)],  # noqa: E731
+                                          1).to(**f).contiguous()
+        paras, nd = sc3(raq, fkt, fkp), sc3(raq_nd, fkt_nd, fkp_nd)
+        scaler = (torch.exp(paras[:, 0] / 10 * 1.80167667 + torch.log(paras[:, 1]) * 0.4330392
+                            + torch.log(paras[:, 2]) * -0.46052953) * 5).contiguous()
+        raq_s = paras[:, 0].contiguous()
+        x = {0: T_prev.to(**f).reshape(B, 1, H, W).contiguous()}
+        dts = {}
+        inp = torch.empty((B, 7, H, W), **f)
+        u = v = p = None
+        for i in range(1, self.ts + 1):
+            L.call("mc_ts_build_input", L.ptr(x[i - 1]), L.ptr(xcp), L.ptr(ycp), L.ptr(yccp), L.ptr(paras), L.ptr(nd), B, H, W,
+                   L.ptr(inp), L.stream())
+            u, v, p = self.stokes(inp)
+            u = u.reshape(B, H, W).contiguous()
+            v = v.reshape(B, H, W).contiguous()
+            Tn, dt_dev = self.ad.step(u, v, x[i - 1].view(B, H, W), xcp, ycp, raq_scalar=raq_s, vel_scale=scaler)
+            x[i] = Tn.view(B, 1, H, W)
+            dts[i] = dt_dev.clone()
+        V = torch.clip(torch.exp(-torch.log(paras[:, 1]).view(B, 1, 1, 1) * x[self.ts - 1]
+                                 + torch.log(paras[:, 2]).view(B, 1, 1, 1) * (1.0 - yccp)), 1e-8, 1.0) if self.ts >= 1 else None
+        sv = scaler.view(B, 1, 1, 1)
+        return (x, dts, u.view(B, 1, H, W) * sv, v.view(B, 1, H, W) * sv,
+                p.reshape(B, 1, H, W) if (p is not None and self.p_pred) else p, V)
+
+
+# --------------------------------------------------------------------------------------------------
 # ConvAE (reference .ipynb_checkpoints/pycold-checkpoint.py:989-1115)
 # --------------------------------------------------------------------------------------------------
 class ConvAE(nn.Module, HipNetMixin):
