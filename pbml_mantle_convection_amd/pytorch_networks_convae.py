@@ -405,8 +405,9 @@ class TS(nn.Module):
     HBM-resident planes (no host round trip inside the loop).  Same constructor and forward signature as the reference;
     returns (x dict, dts dict, u, v, p, V)."""
 
-    def __init__(self, stokes, ad, device, ts=8, advection_scheme=2, scale=True, p_pred=True, net="fluidnet"):
+    def __init__(self, stokes, ad, device, ts=8, advection_scheme=2, scale=True, p_pred=True, net="fluidnet", use_graph=False):
         super().__init__()
+        self.use_graph, self._g = bool(use_graph), None        # use_graph: one rollout step captured as a HIP graph and replayed
         if net not in ("newfluidnet",):
             raise NotImplementedError("TS on the HIP path covers net='newfluidnet' (the deployed configuration)")
         if ad is None:
@@ -430,17 +431,47 @@ class TS(nn.Module):
         raq_s = paras[:, 0].contiguous()
         x = {0: T_prev.to(**f).reshape(B, 1, H, W).contiguous()}
         dts = {}
-        inp = torch.empty((B, 7, H, W), **f)
+        st = self._g if (self._g is not None and self._g["shape"] == (B, H, W)) else None
+        if st is None:
+            st = dict(shape=(B, H, W), inp=torch.empty((B, 7, H, W), **f), T=torch.empty((B, 1, H, W), **f),
+                      Tn=torch.empty((B, H, W), **f), dt=torch.empty(1, **f), graph=None, out=None)
+            self._g = st
+            for k, t in dict(xc=xcp, yc=ycp, ycc=yccp, paras=paras, nd=nd, raq=raq_s, scaler=scaler).items():
+                st[k] = torch.empty_like(t)
+        # the captured step reads these buffers by address: refresh their CONTENTS, never the tensors
+        for k, t in dict(xc=xcp, yc=ycp, ycc=yccp, paras=paras, nd=nd, raq=raq_s, scaler=scaler).items():
+            st[k].copy_(t)
+
+        def one_step():
+            L.call("mc_ts_build_input", L.ptr(st["T"]), L.ptr(st["xc"]), L.ptr(st["yc"]), L.ptr(st["ycc"]), L.ptr(st["paras"]),
+                   L.ptr(st["nd"]), B, H, W, L.ptr(st["inp"]), L.stream())
+            uu, vv, pp = self.stokes(st["inp"])
+            uu = uu.reshape(B, H, W).contiguous()
+            vv = vv.reshape(B, H, W).contiguous()
+            self.ad.step(uu, vv, st["T"].view(B, H, W), st["xc"], st["yc"], raq_scalar=st["raq"], vel_scale=st["scaler"],
+                         out=st["Tn"], dt_out=st["dt"])
+            st["out"] = (uu, vv, pp)
+
         u = v = p = None
         for i in range(1, self.ts + 1):
-            L.call("mc_ts_build_input", L.ptr(x[i - 1]), L.ptr(xcp), L.ptr(ycp), L.ptr(yccp), L.ptr(paras), L.ptr(nd), B, H, W,
-                   L.ptr(inp), L.stream())
-            u, v, p = self.stokes(inp)
-            u = u.reshape(B, H, W).contiguous()
-            v = v.reshape(B, H, W).contiguous()
-            Tn, dt_dev = self.ad.step(u, v, x[i - 1].view(B, H, W), xcp, ycp, raq_scalar=raq_s, vel_scale=scaler)
-            x[i] = Tn.view(B, 1, H, W)
-            dts[i] = dt_dev.clone()
+            st["T"].copy_(x[i - 1])
+            if self.use_graph:
+                if st["graph"] is None:
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        one_step()                                  # warm-up: allocates every buffer outside the capture
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize(dev)
+                    st["graph"] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(st["graph"]):
+                        one_step()
+                st["graph"].replay()
+            else:
+                one_step()
+            u, v, p = st["out"]
+            x[i] = st["Tn"].clone().view(B, 1, H, W)
+            dts[i] = st["dt"].clone()
         V = torch.clip(torch.exp(-torch.log(paras[:, 1]).view(B, 1, 1, 1) * x[self.ts - 1]
                                  + torch.log(paras[:, 2]).view(B, 1, 1, 1) * (1.0 - yccp)), 1e-8, 1.0) if self.ts >= 1 else None
         sv = scaler.view(B, 1, 1, 1)

@@ -271,3 +271,26 @@ def test_ts_rollout_newfluidnet_vs_oracle(golden):
         assert_close(x[i], xr[i].numpy(), atol=5e-5, rtol=0, what=f"T step {i}")
     assert_close(u, ur.numpy(), atol=2e-4 * float(ur.abs().max()), rtol=1e-3, what="u")
     assert_close(V, Vr.numpy(), atol=1e-6, rtol=1e-4, what="V")
+
+
+def test_ts_rollout_graph_replay_equals_eager():
+    """One rollout step captured as a HIP graph and replayed gives bit-identical fields to eager launches, also on a second
+    call with fresh argument tensors (the captured step must read persistent buffers, not the caller's temporaries)."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import ADNet, NewFluidNet, TS
+    torch.manual_seed(1)
+    H, W = 64, 90
+    m = NewFluidNet(3, 7, 8, 3, torch.device(DEV), "gelu", "zeros", "mae", use_symm=True, repeats=2, f=5, p_pred=True).to(DEV)
+    xc, yc = (torch.from_numpy(a) for a in _n3_grid(H, W))
+    res = {}
+    for ug in (False, True):
+        ts = TS(m, ADNet(DEV), DEV, ts=4, net="newfluidnet", use_graph=ug)
+        for rep in range(2):
+            T0 = torch.from_numpy(fields.temperature_field(1, H, W, 77 + rep)).view(1, 1, H, W)
+            args = [torch.tensor(v) for v in (2.5 + rep, 1e7, 30.0)]
+            nd = [torch.tensor(v).view(1, 1, 1, 1) for v in (0.25, 0.26, 0.74)]
+            x, dts, *_ = ts(T0, None, None, yc.clone(), nd[0], nd[1], nd[2], args[0], args[1], args[2], xc.clone(), yc.clone())
+            res[(ug, rep)] = (x[4].clone(), torch.stack([dts[i] for i in range(1, 5)]).clone())
+    for rep in range(2):
+        assert torch.equal(res[(False, rep)][0], res[(True, rep)][0])
+        assert torch.equal(res[(False, rep)][1], res[(True, rep)][1])
+        assert not torch.isnan(res[(True, rep)][0]).any()
