@@ -201,7 +201,7 @@ def main():
         sps = world * B * steps / elapsed
         line = {
             "metric": "training samples/sec (2-D 128x506 Stokes fields, NewFluidNet)" if n1 else
-                      "training samples/sec (2-D 506x506 Stokes fields)", "value": sps, "unit": "samples/s",
+                      f"training samples/sec (2-D {H}x{W} Stokes fields)", "value": sps, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
