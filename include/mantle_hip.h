@@ -184,6 +184,13 @@ int mc_concat_cb8(const void* const* srcs, const int32_t* src_c, int32_t n_src, 
 int mc_gsrc_sum(const mc_grad_src* g0, const mc_grad_src* g1, int32_t n, int32_t c, int32_t h, int32_t w,
                 int32_t dtype, void* out, void* stream);
 
+/* Rectangle copy between CB8 tensors of the same channel count: dst[n][cb][dy+r][dx+c] (=|+=) src[n][cb][sy+r][sx+c] for
+ * r < rh, c < rw; src == NULL writes zeros.  Used to cut the border strips of BoundaryLearnedConvolution2D out of its input
+ * and to frame its output (pytorch_networks_convae.py:1022-1065). */
+int mc_rect_copy(const void* src, int32_t hs, int32_t ws, int32_t sy, int32_t sx, void* dst, int32_t hd, int32_t wd,
+                 int32_t dy, int32_t dx, int32_t rh, int32_t rw, int32_t n, int32_t c, int32_t accumulate, int32_t dtype,
+                 void* stream);
+
 /* ---- resampling (nn.AvgPool2d, nn.Upsample(mode='bicubic'); Unet :2002,2009,2014; ConvAE :1051,1079) */
 int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t f, int32_t dtype,
                    void* out, void* stream);

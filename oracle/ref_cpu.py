@@ -142,6 +142,44 @@ def conv2d_same(x: Tensor, w: Tensor, b: Optional[Tensor], r_p: str, padding=Non
 
 
 # --------------------------------------------------------------------------------------
+# BoundaryLearnedConvolution2D ("learned" padding, pytorch_networks_convae.py:802-1065) — SURVEY.md §8(f) row N4
+# --------------------------------------------------------------------------------------
+LEARNED_BANKS = ("conv", "conv_top_left", "conv_top_right", "conv_bottom_left", "conv_bottom_right", "conv_top",
+                 "conv_bottom", "conv_left", "conv_right")
+
+
+def boundary_learned_conv(sd: Dict[str, Tensor], prefix: str, x: Tensor, k: int, use_symm: bool, bc_x: int = 1,
+                          bc_y: int = 1) -> Tensor:
+    """Nine bias-free VALID convolutions: the main bank on the whole input, eight more on the border strips of width
+    pad = k + 1 + (bc - 1) (k = 5) or k + (bc - 1) (:1025-1026), framed around the main result, plus one shared bias.
+    As in the reference the strip cut from the LAST rows lands in the FIRST output rows and vice versa (:1057-1060)."""
+    c_o = sd[prefix + "learnable_bias"].shape[1]
+    sym = symmetry_counts(c_o)
+
+    def conv(name, t):
+        w = sd[prefix + name + ".weight"]
+        if use_symm:
+            w = expand_symmetric_weight(w, sym)
+        return F.conv2d(t, w)
+
+    pad_x = k + 1 + (bc_x - 1) if k == 5 else k + (bc_x - 1)
+    pad_y = k + 1 + (bc_y - 1) if k == 5 else k + (bc_y - 1)
+    top_left = conv("conv_top_left", x[:, :, :pad_y, :pad_x])
+    bottom_left = conv("conv_bottom_left", x[:, :, -pad_y:, :pad_x])
+    top_right = conv("conv_top_right", x[:, :, :pad_y, -pad_x:])
+    bottom_right = conv("conv_bottom_right", x[:, :, -pad_y:, -pad_x:])
+    top = conv("conv_top", x[:, :, :pad_y, :])
+    left = conv("conv_left", x[:, :, :, :pad_x])
+    bottom = conv("conv_bottom", x[:, :, -pad_y:, :])
+    right = conv("conv_right", x[:, :, :, -pad_x:])
+    y = torch.cat([left, conv("conv", x), right], dim=3)
+    top = torch.cat([top_left, top, top_right], dim=3)
+    bottom = torch.cat([bottom_left, bottom, bottom_right], dim=3)
+    y = torch.cat([bottom, y, top], dim=2)
+    return y + sd[prefix + "learnable_bias"]
+
+
+# --------------------------------------------------------------------------------------
 # FluidLayer (pytorch_networks_convae.py:702-799)
 # --------------------------------------------------------------------------------------
 def gn_groups(c_o: int) -> int:

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mc_gn_act_bwd_apply_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                             _GS, _GS, _vp, _vp, _vp, _vp]),
     "mc_avgpool_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mc_rect_copy": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                               _vp]),
     "mc_concat_cb8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_gsrc_sum": (C.c_int, [_GS, _GS, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_bicubic_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -785,6 +785,25 @@ __global__ void k_bicubic_bwd_xpass(const float* __restrict__ tmp, int C8, int H
   }
 }
 
+template <typename T>
+__global__ void k_rect_copy(const T* __restrict__ src, int hs, int ws, int sy, int sx, T* __restrict__ dst, int hd, int wd,
+                            int dy, int dx, int rh, int rw, int C8, int accumulate) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rh * rw; i += gridDim.x * blockDim.x) {
+    const int r = i / rw, c = i - r * rw;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (src) V8<T>::ld(src + cb8_index(n, cb, sy + r, sx + c, C8, hs, ws), v);
+    T* d = dst + cb8_index(n, cb, dy + r, dx + c, C8, hd, wd);
+    if (accumulate) {
+      float o[8];
+      V8<T>::ld(d, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    V8<T>::st(d, v);
+  }
+}
+
 // =================================================================================================
 // torch.cat along channels of more than two operands; sum of two gradient sources
 // =================================================================================================
@@ -1156,6 +1175,22 @@ int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, true>), g, dim3(256), 0, s, a, (const float*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, partials, blocks, dgamma, dbeta, rows);
   else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, true>), g, dim3(256), 0, s, a, (const bf16_t*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, partials, blocks, dgamma, dbeta, rows);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_rect_copy(const void* src, int32_t hs, int32_t ws, int32_t sy, int32_t sx, void* dst, int32_t hd, int32_t wd,
+                 int32_t dy, int32_t dx, int32_t rh, int32_t rw, int32_t n, int32_t c, int32_t accumulate, int32_t dtype,
+                 void* stream) {
+  if (!dst || n <= 0 || c <= 0 || rh <= 0 || rw <= 0) return MC_EINVAL;
+  if (dy < 0 || dx < 0 || dy + rh > hd || dx + rw > wd) return MC_EINVAL;
+  if (src && (sy < 0 || sx < 0 || sy + rh > hs || sx + rw > ws)) return MC_EINVAL;
+  const int C8 = (c + 7) / 8;
+  dim3 g(max(1, min(cdiv(rh * rw, 256), 512)), C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_rect_copy<float>, g, dim3(256), 0, s, (const float*)src, hs, ws, sy, sx, (float*)dst, hd, wd, dy, dx, rh, rw, C8, accumulate);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_rect_copy<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, hs, ws, sy, sx, (bf16_t*)dst, hd, wd, dy, dx, rh, rw, C8, accumulate);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;

@@ -18,6 +18,7 @@ import torch.optim as optim
 from . import _lib as L
 from .engine import convae_graph, newfluidnet_graph, single_layer_graph, unet_graph
 from .hipnet import HipNetMixin
+from .learned_padding import BoundaryLearnedConvolution2D   # noqa: F401  (reference :802-1065)
 from .symmetric_layers_torch import SymmetricConv2d
 
 _SUPPORTED_ACTS = ("gelu", "relu", "silu", "tanh", "selu", "elu")

@@ -411,3 +411,18 @@ def test_ts_rollout(golden):
     close(smp(u), g["u"], atol=1e-11)
     close(smp(v), g["v"], atol=1e-11)
     close(smp(V), g["V"], atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["k5_symm", "k3_plain"])
+def test_boundary_learned_conv(golden, tag):
+    """the "learned padding" layer (nine valid convolutions framed together) vs the imported reference."""
+    g = golden(f"g16_learned_{tag}")
+    c_i, c_o, k, symm = [int(v) for v in g["meta"]]
+    sd = sd_from(g)
+    x = T(g["x"], True)
+    y = O.boundary_learned_conv(sd, "", x, k, bool(symm))
+    close(y, g["y"])
+    (y * T(g["ct"])).sum().backward()
+    close(x.grad, g["dx"], atol=1e-10)
+    for k_ in sd:
+        close(sd[k_].grad, g["grad/" + k_], atol=1e-10)

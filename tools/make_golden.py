@@ -494,10 +494,25 @@ def g15():
         nd=np.array([0.25, 0.26, 0.74]), paras=np.array([2.5, 1e7, 30.0]))
 
 
+# ------------------------------------------------------------------ G16 BoundaryLearnedConvolution2D
+def g16():
+    for tag, (c_i, c_o, k, symm, H, W) in {"k5_symm": (8, 16, 5, True, 23, 37), "k3_plain": (16, 8, 3, False, 19, 21)}.items():
+        m = P.BoundaryLearnedConvolution2D(c_i, c_o, k, use_symm=symm).double()
+        randomize_(m, 160)
+        with torch.no_grad():
+            m.learnable_bias.copy_((0.1 * torch.randn(m.learnable_bias.shape, generator=torch.Generator().manual_seed(161))).float().double())
+        x = rnd((2, c_i, H, W), 162).requires_grad_(True)
+        y = m(x)
+        ct = rnd(y.shape, 163)
+        (y * ct).sum().backward()
+        npz(f"g16_learned_{tag}", meta=np.array([c_i, c_o, k, int(symm)]), x=x.detach().float(), y=y, ct=ct.float(), dx=x.grad,
+            **sd_np(m), **grads_np(m))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()
