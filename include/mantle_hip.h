@@ -144,6 +144,10 @@ int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int3
                    int32_t dtype, void* stream);
 
 /* ---- GroupNorm + activation (FluidLayer :788-799; Unet :2016-2021) ------------------------ */
+/* Per-tile (sum, sum of squares) partials [n][tiles][ceil(c/8)*8][2] of an existing CB8 tensor, for layers whose output is
+ * assembled from several convolutions (BoundaryLearnedConvolution2D) and cannot take them from one conv epilogue. */
+int mc_gn_partials(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype, int32_t tiles, float* part,
+                   void* stream);
 /* (mean, rstd) per (n, group) from conv stat partials; eps 1e-5, biased variance.  Also emits
  * per-(n,c) means of y when chan_mean != NULL (Unet's spatial zero-mean, :2024). */
 int mc_gn_finalize(const float* stat_partials, int32_t n, int32_t tiles, int32_t c, int32_t groups,

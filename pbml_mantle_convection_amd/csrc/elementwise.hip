@@ -119,6 +119,33 @@ __device__ __forceinline__ void group_channel_sums(const float* __restrict__ par
 }
 __device__ __forceinline__ bool pow2_le64(int v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; }
 
+// (sum, sumsq) partials of a CB8 tensor: block (tile t, channel block cb, image n) sums the rows t, t + tiles, ...
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_partials(const T* __restrict__ y, int C8, int H, int W, int tiles,
+                                                     float* __restrict__ part) {
+  const int t = blockIdx.x, cb = blockIdx.y, n = blockIdx.z;
+  float s[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  const int nrows = (H - t + tiles - 1) / tiles;
+  for (int i = threadIdx.x; i < nrows * W; i += blockDim.x) {
+    const int ry = i / W, xx = i - ry * W, yy = t + ry * tiles;
+    float v[8];
+    V8<T>::ld(y + cb8_index(n, cb, yy, xx, C8, H, W), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[2 * j] += v[j]; s[2 * j + 1] += v[j] * v[j]; }
+  }
+  __shared__ float red[4][16];
+  int idx;
+  float r = wave_sum16(s, threadIdx.x & 63, idx);
+  if ((threadIdx.x & 3) == 0) red[threadIdx.x >> 6][idx] = r;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    part[(((size_t)n * tiles + t) * (C8 * 8) + cb * 8 + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] = tot;
+  }
+}
+
 // one wave per (n, g); also optional per-(n,c) means (block g handles its own channels)
 __global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, int CP, int groups, int hw,
                               float eps, float* __restrict__ stats, float* __restrict__ chan_mean) {
@@ -1004,6 +1031,19 @@ int mc_sum_hw(const float* x, int32_t nc, int32_t hw, float scale, float* out, v
   int chunks = cdiv(hw, 256 * 16);
   if (chunks > 64) chunks = 64;
   hipLaunchKernelGGL(k_sum_hw, dim3(chunks, nc), dim3(256), 0, (hipStream_t)stream, x, hw, scale, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_partials(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype, int32_t tiles, float* part,
+                   void* stream) {
+  if (!y || !part || n <= 0 || c <= 0 || h <= 0 || w <= 0 || tiles <= 0 || tiles > h) return MC_EINVAL;
+  const int C8 = (c + 7) / 8;
+  dim3 g(tiles, C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_partials<float>, g, dim3(256), 0, s, (const float*)y, C8, h, w, tiles, part);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_partials<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)y, C8, h, w, tiles, part);
+  else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

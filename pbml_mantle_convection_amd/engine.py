@@ -44,6 +44,9 @@ class ConvNode:
     pool: int = 1              # AvgPool factor applied to the activated output (1 = none)
     pooled: int = -1           # tensor id of the pooled output
     kind: str = "conv"
+    learned: bool = False      # BoundaryLearnedConvolution2D ("learned padding"): nine valid banks + one shared bias,
+    bc_x: int = 1              # name + {conv, conv_top_left, ...}.weight / name + learnable_bias; bc > 1 widens the
+    bc_y: int = 1              # border strips so that the output grows (Unet's first layer, reference :1995)
 
 
 @dataclass
@@ -263,10 +266,11 @@ def newfluidnet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, 
     return NetGraph(c_i, c_o, ch, nodes, subtract_mean=True, pad_mode=r_p, act=act, divisor=1)
 
 
-def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool) -> NetGraph:
+def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool, learned: bool = False) -> NetGraph:
     """One conv (+GN+act): SymmetricConv2d / FluidLayer used stand-alone."""
     ch = {0: c_in, 1: c_out}
-    node = ConvNode("layers.0." if gn else "", [0], 1, c_out, k, pad, sym_h, post, "layers.1." if gn else None, groups)
+    node = ConvNode("layers.0." if gn else "", [0], 1, c_out, k, pad, sym_h, post, "layers.1." if gn else None, groups,
+                    learned=learned)
     return NetGraph(c_in, c_out, ch, [node], pad_mode=pad_mode, act=act)
 
 
@@ -396,6 +400,11 @@ class Engine:
             h, w = srcs[0].H, srcs[0].W
             for s in srcs:
                 assert (s.H, s.W) == (h, w), "concat sources must agree in size"
+            if node.learned:
+                self.plan.append(self._plan_learned(node, srcs, T, cb8, f32, N, device))
+                e = self.plan[-1]
+                max_dy = max(max_dy, N * e["coutp"] * T[node.out].H * T[node.out].W)
+                continue
             final_f32 = (node.post == L.POST_NONE and node is g.nodes[-1] and self.mc_dtype == L.MC_BF16
                          and node.c_out <= 16)
             d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
@@ -447,10 +456,12 @@ class Engine:
         # prepares dY of layer L-1 (see backward)
         self.dYs = [torch.empty(max_dy, dtype=self.t_dtype, device=device) for _ in range(2)]
         self.dY = self.dYs[0]
-        self.convs = [e for e in self.plan if e["node"].kind == "conv"]
+        self.convs = [e for e in self.plan if e["node"].kind == "conv" and not e["node"].learned]
         self.side = torch.cuda.Stream(device=device)
         last = self.plan[-1]
         assert last["node"].kind == "conv", "graph must end in a conv node"
+        if last["node"].learned and self.mc_dtype == L.MC_BF16:
+            raise NotImplementedError("learned-padding heads in bf16 mode (the last layer's f32 output path) are not implemented")
         self.final_plain = last["node"].post == L.POST_NONE
         assert self.final_plain or not g.subtract_mean
         fo = T[last["node"].out]
@@ -459,6 +470,102 @@ class Engine:
         self.chan_mean = torch.empty((N, g.c_out), **f32) if g.subtract_mean else None
         self.gmean = torch.empty((N, g.c_out), **f32) if g.subtract_mean else None
         self.shape = (N, H, W, str(device))
+
+    # -------------------------------------------------------------- learned padding (BoundaryLearnedConvolution2D)
+    LBANKS = ("conv", "conv_top_left", "conv_top_right", "conv_bottom_left", "conv_bottom_right", "conv_top", "conv_bottom",
+              "conv_left", "conv_right")
+
+    def _plan_learned(self, node, srcs, T, cb8, f32, N, device):
+        """Nine bias-free valid convolutions on the library's conv kernels, the strips cut / the frame assembled with
+        mc_rect_copy (reference pytorch_networks_convae.py:1022-1065).  The gradient w.r.t. the input needs no padded
+        domain: the adjoint of a valid convolution is exactly input-sized."""
+        assert len(srcs) == 1, "learned padding takes one source tensor"
+        s, o = srcs[0], T[node.out]
+        h, w, k = s.H, s.W, node.k
+        pad_x = k + 1 + (node.bc_x - 1) if k == 5 else k + (node.bc_x - 1)
+        pad_y = k + 1 + (node.bc_y - 1) if k == 5 else k + (node.bc_y - 1)
+        fx, fy, mh, mw = pad_x - k + 1, pad_y - k + 1, h - k + 1, w - k + 1
+        if mh < 1 or mw < 1 or pad_x > w or pad_y > h:
+            raise ValueError(f"{node.name}: input {h}x{w} too small for learned padding")
+        ho, wo = mh + 2 * fy, mw + 2 * fx
+        o.H, o.W = ho, wo
+        regs = {"conv": (0, 0, h, w, fy, fx),
+                "conv_left": (0, 0, h, pad_x, fy, 0), "conv_right": (0, w - pad_x, h, pad_x, fy, fx + mw),
+                "conv_bottom": (h - pad_y, 0, pad_y, w, 0, fx), "conv_top": (0, 0, pad_y, w, fy + mh, fx),
+                "conv_bottom_left": (h - pad_y, 0, pad_y, pad_x, 0, 0),
+                "conv_bottom_right": (h - pad_y, w - pad_x, pad_y, pad_x, 0, fx + mw),
+                "conv_top_left": (0, 0, pad_y, pad_x, fy + mh, 0), "conv_top_right": (0, w - pad_x, pad_y, pad_x, fy + mh, fx + mw)}
+        banks = {}
+        for name, (sy, sx, sh, sw, dy, dx) in regs.items():
+            d = L.ConvDesc(N, sh, sw, s.C, 0, node.c_out, k, 0, L.PAD_MODES["zeros"], self.mc_dtype, node.sym_h, 0, 0)
+            rh, rw = sh - k + 1, sw - k + 1
+            dd = L.ConvDesc(N, rh, rw, node.c_out, 0, s.C, k, k - 1, 0, self.mc_dtype, 0, 0, 0)
+            if L.call("mc_conv_tiles", C.byref(d)) <= 0:
+                raise L.MantleHipError(f"unsupported convolution configuration for {node.name}{name}")
+            u8 = dict(dtype=torch.uint8, device=device)
+            banks[name] = dict(desc=d, ddesc=dd, reg=(sy, sx, sh, sw, dy, dx), rh=rh, rw=rw,
+                               S=None if name == "conv" else cb8(s.C, sh, sw), R=cb8(node.c_out, rh, rw),
+                               dR=cb8(node.c_out, rh, rw), dS=cb8(s.C, sh, sw),
+                               bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), **u8),
+                               dbank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 1), **u8),
+                               wpart=torch.empty(L.call("mc_wgrad_partial_bytes", C.byref(d)), **u8))
+        coutp = ((node.c_out + 7) // 8) * 8
+        tiles = min(64, ho)
+        e = dict(node=node, banks=banks, tiles=tiles, coutp=coutp, Y=cb8(node.c_out, ho, wo),
+                 part=torch.empty((N, tiles, coutp, 2), **f32), need_dgrad=s.requires_grad, dxl=cb8(s.C, h, w), desc=None)
+        o.buf = cb8(node.c_out, ho, wo) if node.post != L.POST_NONE else e["Y"]
+        if node.post == L.POST_GN_ACT:
+            e["stats"] = torch.empty((N, node.groups, 2), **f32)
+            e["gblocks"] = L.call("mc_gn_bwd_blocks", ho, wo)
+            e["gpart"] = torch.empty((N, e["gblocks"], coutp, 2), **f32)
+            e["m12"] = torch.empty((N, node.groups, 2), **f32)
+        if node.pool > 1:
+            p = T[node.pooled]
+            p.H, p.W = ho // node.pool, wo // node.pool
+            p.buf = cb8(node.c_out, p.H, p.W)
+        return e
+
+    def _learned_forward(self, e, src, params, need_part, st):
+        node, N = e["node"], self.N
+        bias = self._param(params, node.name + "learnable_bias")
+        o_h, o_w = e["Y"].shape[2], e["Y"].shape[3]
+        for name, b in e["banks"].items():
+            sy, sx, sh, sw, dy, dx = b["reg"]
+            w = self._param(params, node.name + name + ".weight")
+            xin = src.buf
+            if b["S"] is not None:
+                L.call("mc_rect_copy", L.ptr(src.buf), src.H, src.W, sy, sx, L.ptr(b["S"]), sh, sw, 0, 0, sh, sw, N, src.C, 0,
+                       self.mc_dtype, st)
+                xin = b["S"]
+            L.call("mc_pack_weights", C.byref(b["desc"]), L.ptr(w), 0, L.ptr(b["bank"]), st)
+            L.call("mc_conv2d", C.byref(b["desc"]), L.ptr(xin), None, L.ptr(b["bank"]), L.ptr(bias), L.ptr(b["R"]), None, None, st)
+            L.call("mc_rect_copy", L.ptr(b["R"]), b["rh"], b["rw"], 0, 0, L.ptr(e["Y"]), o_h, o_w, dy, dx, b["rh"], b["rw"], N,
+                   node.c_out, 0, self.mc_dtype, st)
+        if need_part:
+            L.call("mc_gn_partials", L.ptr(e["Y"]), N, node.c_out, o_h, o_w, self.mc_dtype, e["tiles"], L.ptr(e["part"]), st)
+
+    def _learned_backward(self, e, src, dY, params, grads, st):
+        node, N = e["node"], self.N
+        o_h, o_w = e["Y"].shape[2], e["Y"].shape[3]
+        db = grads[node.name + "learnable_bias"]
+        for name, b in e["banks"].items():                      # "conv" comes first: its input gradient initialises dxl
+            sy, sx, sh, sw, dy, dx = b["reg"]
+            L.call("mc_rect_copy", L.ptr(dY), o_h, o_w, dy, dx, L.ptr(b["dR"]), b["rh"], b["rw"], 0, 0, b["rh"], b["rw"], N, node.c_out,
+                   0, self.mc_dtype, st)
+            xin = src.buf if b["S"] is None else b["S"]
+            L.call("mc_conv2d_wgrad", C.byref(b["desc"]), L.ptr(xin), None, L.ptr(b["dR"]), L.ptr(b["wpart"]), st)
+            L.call("mc_conv2d_wgrad_finalize", C.byref(b["desc"]), L.ptr(b["wpart"]), L.ptr(grads[node.name + name + ".weight"]),
+                   L.ptr(db), st)
+            if e["need_dgrad"]:
+                w = self._param(params, node.name + name + ".weight")
+                L.call("mc_pack_weights", C.byref(b["desc"]), L.ptr(w), 1, L.ptr(b["dbank"]), st)
+                tgt = e["dxl"] if name == "conv" else b["dS"]
+                L.call("mc_conv2d", C.byref(b["ddesc"]), L.ptr(b["dR"]), None, L.ptr(b["dbank"]), None, L.ptr(tgt), None, None, st)
+                if name != "conv":
+                    L.call("mc_rect_copy", L.ptr(b["dS"]), sh, sw, 0, 0, L.ptr(e["dxl"]), src.H, src.W, sy, sx, sh, sw, N, src.C, 1,
+                           self.mc_dtype, st)
+        if e["need_dgrad"]:
+            src.gsrcs.append(L.GradSrc(L.ptr(e["dxl"]), L.GSRC_PLAIN, 0, 0, 1, src.H, src.W))
 
     def _table(self, n_in, n_out):
         key = (n_in, n_out)
@@ -513,16 +620,20 @@ class Engine:
                        L.ptr(wx), self.mc_dtype, L.ptr(o.buf), st)
                 continue
             d = e["desc"]
-            w = self._param(params, node.name + "weight")
-            b = self._param(params, node.name + "bias")
+            if not node.learned:
+                w = self._param(params, node.name + "weight")
+                b = self._param(params, node.name + "bias")
             srcs = [T[i] for i in node.srcs]
             o = T[node.out]
             final = node.post == L.POST_NONE
             need_part = node.post == L.POST_GN_ACT or (final and g.subtract_mean)
-            self._probe_begin()
-            L.call("mc_conv2d", C.byref(d), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf) if len(srcs) > 1 else None,
-                   L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None, L.ptr(e["part"]) if need_part else None, st)
-            self._probe_end(d, "fwd " + node.name)
+            if node.learned:
+                self._learned_forward(e, srcs[0], params, need_part, st)
+            else:
+                self._probe_begin()
+                L.call("mc_conv2d", C.byref(d), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf) if len(srcs) > 1 else None,
+                       L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None, L.ptr(e["part"]) if need_part else None, st)
+                self._probe_end(d, "fwd " + node.name)
             if node.post == L.POST_GN_ACT:
                 L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
                        L.ptr(e["stats"]), None, st)
@@ -656,6 +767,10 @@ class Engine:
                     L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
                            self.mc_dtype, g0, g1, L.ptr(dY), st)
+            if node.learned:
+                self._learned_backward(e, srcs[0], dY, params, grads, st)
+                k += 1
+                continue
             x0 = L.ptr(srcs[0].buf)
             x1 = L.ptr(srcs[1].buf) if len(srcs) > 1 else None
             side = self.side if (self.overlap_wgrad == 1 or (self.overlap_wgrad == 2 and o.H * o.W <= 128 * 128)) else main
@@ -710,6 +825,8 @@ class Engine:
             if e["need_dgrad"]:
                 jobs.append((e["desc"], L.ptr(w), 1, L.ptr(e["dbank"])))
         n = len(jobs)
+        if n == 0:
+            return                                           # (a graph of learned-padding layers only)
         descs = (L.ConvDesc * n)(*[j[0] for j in jobs])
         ws = (C.c_void_p * n)(*[j[1] for j in jobs])
         dg = (C.c_int32 * n)(*[j[2] for j in jobs])

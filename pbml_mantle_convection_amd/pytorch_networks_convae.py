@@ -139,9 +139,8 @@ def _check_common(act_fn, r_p, dilation, drop_rate=0.0, spectral_conv=False, blu
     if act_fn not in _SUPPORTED_ACTS:
         raise NotImplementedError(f"act_fn={act_fn!r}: supported on the HIP path: {_SUPPORTED_ACTS} "
                                   "('sine' is undefined in the reference itself)")
-    if r_p not in ("zeros", "replicate", "reflect"):
-        raise NotImplementedError(f"r_p={r_p!r}: the HIP path implements zeros / replicate / reflect padding "
-                                  "('learned' padding is a different operator, out of scope)")
+    if r_p not in ("zeros", "replicate", "reflect", "learned"):
+        raise NotImplementedError(f"r_p={r_p!r}: the HIP path implements zeros / replicate / reflect / learned padding")
     if dilation != 1:
         raise NotImplementedError("dilation != 1 is not implemented on the HIP path")
     if drop_rate not in (0, 0.0):
@@ -161,17 +160,23 @@ class FluidLayer(nn.Module, HipNetMixin):
         self.act_fn = act_fn
         self.layers = nn.ModuleList()
         h_s = int(c_o / 4) if c_o > 4 else int(c_o / 2)
-        if use_symm:
+        if r_p == "learned":
+            self.layers.append(BoundaryLearnedConvolution2D(c_i, c_o, k=f, use_symm=use_symm))      # reference :760-763
+        elif use_symm:
             self.layers.append(SymmetricConv2d(c_i, c_o, kernel_size=f, padding="same", dilation=dilation,
                                                padding_mode=r_p, symmetry={"h": h_s, "v": 0, "hv": 0}))
         else:
             self.layers.append(nn.Conv2d(c_i, c_o, kernel_size=f, padding="same", dilation=dilation,
                                          padding_mode=r_p))
         self.layers.append(torch.nn.GroupNorm(int(c_o / min(4, c_o)), c_o))
-        self._init_hipnet(single_layer_graph(c_i, c_o, f, f // 2, r_p, h_s if use_symm else 0, L.POST_GN_ACT,
-                                             act_fn, int(c_o / min(4, c_o)), gn=True))
+        self._init_hipnet(single_layer_graph(c_i, c_o, f, f // 2, "zeros" if r_p == "learned" else r_p,
+                                             h_s if use_symm else 0, L.POST_GN_ACT, act_fn, int(c_o / min(4, c_o)), gn=True,
+                                             learned=(r_p == "learned")))
 
     def forward(self, inputs, bc_x=1, bc_y=1):
+        if self.r_p == "learned" and (bc_x != 1 or bc_y != 1):
+            raise NotImplementedError("a stand-alone FluidLayer runs the learned padding with bc_x = bc_y = 1 (inside the Unet "
+                                      "graph the first layer's bc_x = 4 is part of the graph)")
         return self._run_graph(inputs)
 
 

@@ -318,3 +318,27 @@ def test_boundary_learned_conv_vs_golden(golden, tag):
         assert_close(p.grad, ref, atol=2e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
     with pytest.raises(NotImplementedError):
         m(x, bc_x=4)
+
+
+def test_fluidlayer_learned_padding_vs_golden(golden):
+    """FluidLayer(r_p='learned'): learned-padding conv -> GroupNorm (statistics of the assembled output) -> GELU, through the
+    engine's learned node, forward and all gradients against the reference."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import FluidLayer
+    g = golden("g16_learned_fluidlayer")
+    m = FluidLayer(8, 16, "gelu", "learned", True, 1, f=5)
+    sd = {n[3:]: torch.from_numpy(g[n]).float() for n in g.files if n.startswith("sd/")}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = dev(g["x"]).requires_grad_(True)
+    y = m(x)
+    assert_close(y, g["y"], atol=3e-5 * max(1.0, float(np.abs(g["y"]).max())), rtol=1e-4, what="y")
+    (y * dev(g["ct"])).sum().backward()
+    # (the engine does not produce the gradient w.r.t. a network's input; the stand-alone BoundaryLearnedConvolution2D does)
+    for n, p in m.named_parameters():
+        ref = g["grad/" + n]
+        if n == "layers.0.learnable_bias":
+            continue              # GroupNorm cancels a per-channel constant only per group: compared below with a loose floor
+        assert_close(p.grad, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
+    ref = g["grad/layers.0.learnable_bias"]
+    assert_close(m.layers[0].learnable_bias.grad, ref, atol=2e-3 * max(1.0, float(np.abs(ref).max())), rtol=5e-3, what="bias grad")

@@ -507,6 +507,14 @@ def g16():
         (y * ct).sum().backward()
         npz(f"g16_learned_{tag}", meta=np.array([c_i, c_o, k, int(symm)]), x=x.detach().float(), y=y, ct=ct.float(), dx=x.grad,
             **sd_np(m), **grads_np(m))
+    # the FluidLayer around it (conv -> GroupNorm -> GELU, :790-799)
+    m = P.FluidLayer(8, 16, "gelu", "learned", True, 1, f=5).double()
+    randomize_(m, 165)
+    x = rnd((2, 8, 23, 37), 166).requires_grad_(True)
+    y = m(x)
+    ct = rnd(y.shape, 167)
+    (y * ct).sum().backward()
+    npz("g16_learned_fluidlayer", x=x.detach().float(), y=y, ct=ct.float(), dx=x.grad, **sd_np(m), **grads_np(m))
 
 
 if __name__ == "__main__":
