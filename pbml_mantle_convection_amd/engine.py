@@ -98,7 +98,10 @@ def _groups(c_o: int) -> int:
 
 
 def unet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f) -> NetGraph:
-    """Layer wiring of Unet.__init__/forward (reference pytorch_networks_convae.py:1842-2024)."""
+    """Layer wiring of Unet.__init__/forward (reference pytorch_networks_convae.py:1842-2024).  r_p = 'learned': every
+    conv is a BoundaryLearnedConvolution2D node; the input is not padded — the first layer's bc_x = 4 strips grow the field
+    by the same 3 + 3 columns (:1990-1997) — and the two-operand concats are materialised (CatNode)."""
+    learned = r_p == "learned"
     ch: Dict[int, int] = {0: c_i}
     nodes = []
     nid = [0]
@@ -108,10 +111,18 @@ def unet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f) -> NetG
         ch[nid[0]] = c
         return nid[0]
 
-    def fluid(prefix, srcs, c_out, pool=1):
+    def one_src(srcs):
+        if not learned or len(srcs) == 1:
+            return list(srcs)
+        cat = new(sum(ch[i] for i in srcs))
+        nodes.append(CatNode(list(srcs), cat))
+        return [cat]
+
+    def fluid(prefix, srcs, c_out, pool=1, bc_x=1):
+        srcs = one_src(srcs)
         out = new(c_out)
         node = ConvNode(prefix + "layers.0.", list(srcs), out, c_out, f, f // 2, _sym_h(c_out) if use_symm else 0,
-                        L.POST_GN_ACT, prefix + "layers.1.", _groups(c_out), pool)
+                        L.POST_GN_ACT, prefix + "layers.1.", _groups(c_out), pool, learned=learned, bc_x=bc_x)
         if pool > 1:
             node.pooled = new(c_out)
         nodes.append(node)
@@ -121,7 +132,7 @@ def unet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f) -> NetG
     cur = 0
     for r in range(repeats):
         last = r == repeats - 1
-        n = fluid(f"conv.{r}.", [cur], c_h, pool=2 if (last and levels > 1) else 1)
+        n = fluid(f"conv.{r}.", [cur], c_h, pool=2 if (last and levels > 1) else 1, bc_x=4 if (learned and r == 0) else 1)
         cur = n.out
     feat[0] = n
     c = c_h
@@ -151,14 +162,18 @@ def unet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f) -> NetG
     else:
         raise ValueError("Unet needs levels >= 2")
     R = repeats
-    o = new(c)
-    nodes.append(ConvNode(f"conv.{R}.", head_srcs, o, c, f, f // 2, 0, L.POST_GN_ACT, "gn.0.", int(c / 4)))
-    o2 = new(c)
-    nodes.append(ConvNode(f"conv.{R + 1}.", [o], o2, c, f, f // 2, 0, L.POST_ACT, None, 1))
-    o3 = new(c_o)
-    nodes.append(ConvNode(f"conv.{R + 2}.", [o2], o3, c_o, f, f // 2, 0, L.POST_NONE, None, 1))
-    return NetGraph(c_i, c_o, ch, nodes, in_pad_w=3, crop_w=3, subtract_mean=True, pad_mode=r_p, act=act,
-                    divisor=1)
+
+    def head(name, srcs, c_out, post, gn_name, groups):
+        o = new(c_out)
+        nodes.append(ConvNode(name, one_src(srcs), o, c_out, f, f // 2, (_sym_h(c_out) if use_symm else 0) if learned else 0,
+                              post, gn_name, groups, learned=learned))
+        return o
+
+    o = head(f"conv.{R}.", head_srcs, c, L.POST_GN_ACT, "gn.0.", int(c / 4))
+    o2 = head(f"conv.{R + 1}.", [o], c, L.POST_ACT, None, 1)
+    head(f"conv.{R + 2}.", [o2], c_o, L.POST_NONE, None, 1)
+    return NetGraph(c_i, c_o, ch, nodes, in_pad_w=0 if learned else 3, crop_w=3, subtract_mean=True,
+                    pad_mode="zeros" if learned else r_p, act=act, divisor=1)
 
 
 def convae_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, loss_type) -> NetGraph:
@@ -223,6 +238,7 @@ def newfluidnet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, 
     pooling the previous level once more, which is what the graph does."""
     if c_h % 8:
         raise NotImplementedError("the HIP path of NewFluidNet needs c_h to be a multiple of 8 (channel-block concat)")
+    learned = r_p == "learned"          # every conv a BoundaryLearnedConvolution2D; the head then uses k = f (reference :1296-1313)
     ch: Dict[int, int] = {0: c_i}
     nodes = []
     nid = [0]
@@ -235,7 +251,7 @@ def newfluidnet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, 
     def fluid(prefix, src, c_out):
         out = new(c_out)
         node = ConvNode(prefix + "layers.0.", [src], out, c_out, f, f // 2, _sym_h(c_out) if use_symm else 0,
-                        L.POST_GN_ACT, prefix + "layers.1.", _groups(c_out))
+                        L.POST_GN_ACT, prefix + "layers.1.", _groups(c_out), learned=learned)
         nodes.append(node)
         return node
 
@@ -257,13 +273,18 @@ def newfluidnet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, 
         outs.append(cur)
     cat = new(c_h * levels + c_i)
     nodes.append(CatNode(outs + [0], cat))
+    hk = f if learned else 3
+
+    def hsym(c):
+        return (_sym_h(c) if use_symm else 0) if learned else 0
+
     o = new(c_h)
-    nodes.append(ConvNode("conv.1.", [cat], o, c_h, 3, 1, 0, L.POST_GN_ACT, "gn.0.", int(c_h / 4)))
+    nodes.append(ConvNode("conv.1.", [cat], o, c_h, hk, hk // 2, hsym(c_h), L.POST_GN_ACT, "gn.0.", int(c_h / 4), learned=learned))
     o2 = new(c_h)
-    nodes.append(ConvNode("conv.2.", [o], o2, c_h, 3, 1, 0, L.POST_ACT, None, 1))
+    nodes.append(ConvNode("conv.2.", [o], o2, c_h, hk, hk // 2, hsym(c_h), L.POST_ACT, None, 1, learned=learned))
     o3 = new(c_o)
-    nodes.append(ConvNode("conv.3.", [o2], o3, c_o, 3, 1, 0, L.POST_NONE, None, 1))
-    return NetGraph(c_i, c_o, ch, nodes, subtract_mean=True, pad_mode=r_p, act=act, divisor=1)
+    nodes.append(ConvNode("conv.3.", [o2], o3, c_o, hk, hk // 2, hsym(c_o), L.POST_NONE, None, 1, learned=learned))
+    return NetGraph(c_i, c_o, ch, nodes, subtract_mean=True, pad_mode="zeros" if learned else r_p, act=act, divisor=1)
 
 
 def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool, learned: bool = False) -> NetGraph:
@@ -741,8 +762,9 @@ class Engine:
                 if node.pool > 1:
                     p = T[node.pooled]
                     for q in p.gsrcs:
-                        assert q.kind == L.GSRC_PADFOLD, "a pooled tensor feeds exactly one conv"
-                        gs.append(L.GradSrc(q.ptr, L.GSRC_PADFOLD_POOL, q.pad, q.pad_mode, node.pool, p.H, p.W))
+                        assert q.kind in (L.GSRC_PADFOLD, L.GSRC_PLAIN) and q.c8_total == 0, "a pooled tensor feeds exactly one conv"
+                        kind = L.GSRC_PADFOLD_POOL if q.kind == L.GSRC_PADFOLD else L.GSRC_PLAIN_POOL   # (PLAIN: learned-padding conv)
+                        gs.append(L.GradSrc(q.ptr, kind, q.pad, q.pad_mode, node.pool, p.H, p.W))
                 assert 1 <= len(gs) <= 2, f"{node.name}: {len(gs)} gradient sources"
                 g0 = C.byref(gs[0])
                 g1 = C.byref(gs[1]) if len(gs) > 1 else None

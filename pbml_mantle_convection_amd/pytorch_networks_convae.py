@@ -254,10 +254,16 @@ class Unet(nn.Module, HipNetMixin):
             for r in range(repeats):
                 self.upconvs[-1].append(fl(c + int(c / 2) if r == 0 else int(c / 2), int(c / 2)))
             c = int(c / 2)
-        self.conv.append(nn.Conv2d(int(c * 2), c, kernel_size=f, padding="same", dilation=dilation, padding_mode=r_p))
-        self.gn.append(torch.nn.GroupNorm(int(c / 4), c))
-        self.conv.append(nn.Conv2d(c, c, kernel_size=f, padding="same", padding_mode=r_p))
-        self.conv.append(nn.Conv2d(c, c_o, kernel_size=f, padding="same", padding_mode=r_p))
+        if r_p == "learned":                                                   # reference :1946-1983
+            self.conv.append(BoundaryLearnedConvolution2D(int(c * 2), c, k=f, use_symm=use_symm))
+            self.gn.append(torch.nn.GroupNorm(int(c / 4), c))
+            self.conv.append(BoundaryLearnedConvolution2D(c, c, k=f, use_symm=use_symm))
+            self.conv.append(BoundaryLearnedConvolution2D(c, c_o, k=f, use_symm=use_symm))
+        else:
+            self.conv.append(nn.Conv2d(int(c * 2), c, kernel_size=f, padding="same", dilation=dilation, padding_mode=r_p))
+            self.gn.append(torch.nn.GroupNorm(int(c / 4), c))
+            self.conv.append(nn.Conv2d(c, c, kernel_size=f, padding="same", padding_mode=r_p))
+            self.conv.append(nn.Conv2d(c, c_o, kernel_size=f, padding="same", padding_mode=r_p))
         self._init_hipnet(graph)
 
     def features(self, inputs):
@@ -342,10 +348,16 @@ class NewFluidNet(nn.Module, HipNetMixin):
             self.convs.append(nn.ModuleList())
             for r in range(repeats):
                 self.convs[l].append(fl(c_h, c_h))
-        self.conv.append(nn.Conv2d(c_h * levels + c_i, c_h, kernel_size=3, padding=(1, 1), dilation=dilation, padding_mode=r_p))
-        self.gn.append(torch.nn.GroupNorm(int(c_h / 4), c_h))
-        self.conv.append(nn.Conv2d(c_h, c_h, kernel_size=3, padding=(1, 1), padding_mode=r_p))
-        self.conv.append(nn.Conv2d(c_h, c_o, kernel_size=3, padding=(1, 1), padding_mode=r_p))
+        if r_p == "learned":                                                   # reference :1268-1313
+            self.conv.append(BoundaryLearnedConvolution2D(c_h * levels + c_i, c_h, k=f, use_symm=use_symm))
+            self.gn.append(torch.nn.GroupNorm(int(c_h / 4), c_h))
+            self.conv.append(BoundaryLearnedConvolution2D(c_h, c_h, k=f, use_symm=use_symm))
+            self.conv.append(BoundaryLearnedConvolution2D(c_h, c_o, k=f, use_symm=use_symm))
+        else:
+            self.conv.append(nn.Conv2d(c_h * levels + c_i, c_h, kernel_size=3, padding=(1, 1), dilation=dilation, padding_mode=r_p))
+            self.gn.append(torch.nn.GroupNorm(int(c_h / 4), c_h))
+            self.conv.append(nn.Conv2d(c_h, c_h, kernel_size=3, padding=(1, 1), padding_mode=r_p))
+            self.conv.append(nn.Conv2d(c_h, c_o, kernel_size=3, padding=(1, 1), padding_mode=r_p))
         self._init_hipnet(graph)
 
     def features(self, inputs):

@@ -92,7 +92,7 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         FluidLayer(4, 8, act_fn="sine")
     with pytest.raises(NotImplementedError):
-        FluidLayer(4, 8, r_p="learned")
+        FluidLayer(4, 8, r_p="circular")
     with pytest.raises(NotImplementedError):
         Unet(3, 10, 8, 3, spectral_conv=True)
     with pytest.raises(NotImplementedError):

@@ -342,3 +342,56 @@ def test_fluidlayer_learned_padding_vs_golden(golden):
         assert_close(p.grad, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
     ref = g["grad/layers.0.learnable_bias"]
     assert_close(m.layers[0].learnable_bias.grad, ref, atol=2e-3 * max(1.0, float(np.abs(ref).max())), rtol=5e-3, what="bias grad")
+
+
+def test_unet_learned_padding_vs_golden(golden):
+    """the U-Net with r_p='learned' (every conv a BoundaryLearnedConvolution2D, the first layer's bc_x = 4
+    strips growing the field instead of F.pad, materialised concats) forward + every parameter gradient vs the reference."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    g = golden("g17_unet_learned")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm = [int(v) for v in g["cfg"]]
+    m = Unet(levels, c_i, c_h, c_o, torch.device(DEV), "gelu", "learned", "mae", use_symm=bool(symm), repeats=repeats, f=f,
+             p_pred=bool(p_pred))
+    sd = {n[3:]: torch.from_numpy(g[n]).float() for n in g.files if n.startswith("sd/")}
+    assert {n: tuple(v.shape) for n, v in m.state_dict().items()} == {n: tuple(v.shape) for n, v in sd.items()}
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    outs = m(dev(fields.unet_input(2, 40, 54, 172, c_i=c_i)))
+    loss = 0.0
+    for n, o in zip("uvpT", outs):
+        ref = g["out/" + n]
+        assert tuple(o.shape) == ref.shape
+        assert_close(o, ref, atol=3e-5 * max(1.0, float(np.abs(ref).max())), rtol=2e-4, what="out " + n)
+        loss = loss + (o * dev(g["ct/" + n])).sum()
+    loss.backward()
+    for n, p in m.named_parameters():
+        ref = g["grad/" + n]
+        if float(np.abs(ref).max()) < 1e-6:
+            continue                                    # null directions (the last layer's shared bias under the zero-mean)
+        assert_close(p.grad, ref, atol=5e-4 * max(1.0, float(np.abs(ref).max())), rtol=3e-3, what="grad " + n)
+
+
+def test_newfluidnet_learned_padding_vs_golden(golden):
+    """SURVEY 8(f) N4 x N1: NewFluidNet with r_p='learned' (learned-padding FluidLayers and a 5 x 5 learned-padding head)."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import NewFluidNet
+    g = golden("g17_newfluidnet_learned")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm = [int(v) for v in g["cfg"]]
+    m = NewFluidNet(levels, c_i, c_h, c_o, torch.device(DEV), "gelu", "learned", "mae", use_symm=bool(symm), repeats=repeats, f=f,
+                    p_pred=bool(p_pred))
+    sd = {n[3:]: torch.from_numpy(g[n]).float() for n in g.files if n.startswith("sd/")}
+    assert {n: tuple(v.shape) for n, v in m.state_dict().items()} == {n: tuple(v.shape) for n, v in sd.items()}
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    outs = m(dev(fields.unet_input(1, 128, 506, 176, c_i=c_i)))
+    loss = 0.0
+    for n, o in zip("uvp", outs):
+        ref = g["out/" + n]
+        assert_close(fields.strided_sample(o.detach().cpu().numpy(), 20001), ref, atol=3e-5 * max(1.0, float(np.abs(ref).max())),
+                     rtol=2e-4, what="out " + n)
+        loss = loss + (o * dev(g["ct/" + n])).sum()
+    loss.backward()
+    for n, p in m.named_parameters():
+        ref = g["grad/" + n]
+        if float(np.abs(ref).max()) < 1e-6:
+            continue
+        assert_close(p.grad, ref, atol=5e-4 * max(1.0, float(np.abs(ref).max())), rtol=3e-3, what="grad " + n)

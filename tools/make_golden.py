@@ -517,10 +517,48 @@ def g16():
     npz("g16_learned_fluidlayer", x=x.detach().float(), y=y, ct=ct.float(), dx=x.grad, **sd_np(m), **grads_np(m))
 
 
+# ------------------------------------------------------------------ G17 Unet with learned padding
+def g17():
+    m = P.Unet(3, 10, 8, 4, CPU, "gelu", "learned", "mae", use_symm=True, repeats=2, f=5, p_pred=True).double()
+    randomize_(m, 170)
+    with torch.no_grad():
+        g_ = torch.Generator().manual_seed(171)
+        for n, p in m.named_parameters():
+            if n.endswith("learnable_bias"):
+                p.copy_((0.1 * torch.randn(p.shape, generator=g_)).float().double())
+    x = torch.from_numpy(fields.unet_input(2, 40, 54, 172, c_i=10)).requires_grad_(True)
+    outs = m(x)
+    loss, save = 0.0, {}
+    for n, o in zip("uvpT", outs):
+        ct = rnd(o.shape, 173 + len(save))
+        loss = loss + (o * ct).sum()
+        save["out/" + n] = o
+        save["ct/" + n] = ct.float()
+    loss.backward()
+    # (no CPU restatement of the learned-padding Unet: these vectors pin the GPU path only, f32 is enough)
+    save = {k_: v.detach().float() for k_, v in save.items()}
+    npz("g17_unet_learned", cfg=np.array([3, 10, 8, 4, 2, 5, 1, 1]), **save, **sd_np(m),
+        **{k_: v.float() for k_, v in grads_np(m).items()})
+    # NewFluidNet with learned padding (two levels: 128x506 and 64x253)
+    m = P.NewFluidNet(2, 7, 8, 4, CPU, "gelu", "learned", "mae", use_symm=True, repeats=1, f=5, p_pred=True).double()
+    randomize_(m, 175)
+    x = torch.from_numpy(fields.unet_input(1, 128, 506, 176, c_i=7)).requires_grad_(True)
+    outs = m(x)
+    loss, save = 0.0, {}
+    for n, o in zip("uvp", outs):
+        ct = rnd(o.shape, 177 + len(save))
+        loss = loss + (o * ct).sum()
+        save["out/" + n] = fields.strided_sample(o.detach().numpy(), 20001).astype(np.float32)
+        save["ct/" + n] = ct.float()
+    loss.backward()
+    npz("g17_newfluidnet_learned", cfg=np.array([2, 7, 8, 4, 1, 5, 1, 1]), **save, **sd_np(m),
+        **{k_: v.float() for k_, v in grads_np(m).items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17):
         if not only or fn.__name__ in only:
             fn()
