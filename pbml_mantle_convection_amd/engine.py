@@ -481,8 +481,6 @@ class Engine:
         self.side = torch.cuda.Stream(device=device)
         last = self.plan[-1]
         assert last["node"].kind == "conv", "graph must end in a conv node"
-        if last["node"].learned and self.mc_dtype == L.MC_BF16:
-            raise NotImplementedError("learned-padding heads in bf16 mode (the last layer's f32 output path) are not implemented")
         self.final_plain = last["node"].post == L.POST_NONE
         assert self.final_plain or not g.subtract_mean
         fo = T[last["node"].out]

@@ -251,3 +251,24 @@ def test_newfluidnet_bf16_vs_golden(golden, tag):
     # noise dominates (tools/diag_newfluidnet.py: fp32 mode 1e-5, bf16 mode 0.2-0.7 per parameter on this random SELU net):
     # for the 'curl' case only the direction of the concatenated gradient is asserted
     assert (num / den) ** 0.5 < (0.6 if str(g["loss_type"]) == "curl" else 0.2), (num / den) ** 0.5
+
+
+def test_unet_learned_padding_bf16_vs_golden(golden):
+    """SURVEY 8(f) N4 in bf16 mode (the learned-padding head stores its output in bf16: no f32 last-layer path there)."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    g = golden("g17_unet_learned")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm = [int(v) for v in g["cfg"]]
+    m = Unet(levels, c_i, c_h, c_o, torch.device(DEV), "gelu", "learned", "mae", use_symm=bool(symm), repeats=repeats, f=f,
+             p_pred=bool(p_pred))
+    m.load_state_dict({n[3:]: torch.from_numpy(g[n]).float() for n in g.files if n.startswith("sd/")})
+    m = m.to(DEV).set_precision("bf16")
+    outs = m(dev(fields.unet_input(2, 40, 54, 172, c_i=c_i)))
+    loss = 0.0
+    for n, o in zip("uvpT", outs):
+        ref = g["out/" + n]
+        assert float(np.abs(o.detach().double().cpu().numpy() - ref).mean()) <= 0.12 * float(np.abs(ref).mean()), n
+        loss = loss + (o * dev(g["ct/" + n])).sum()
+    loss.backward()
+    num = sum(float((p.grad.double().cpu() - torch.from_numpy(g["grad/" + n]).double()).norm() ** 2) for n, p in m.named_parameters())
+    den = sum(float(np.linalg.norm(g["grad/" + n].astype(np.float64)) ** 2) for n, _ in m.named_parameters())
+    assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5
