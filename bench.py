@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    p.add_argument("--r-p", type=str, default=None, choices=["zeros", "replicate", "reflect", "learned"],
+                   help="padding of the conv layers (default: reflect for cfg3, zeros for newfluidnet; 'learned' = SURVEY 8f N4)")
     p.add_argument("--workload", type=str, default="cfg3", choices=["cfg3", "newfluidnet"],
                    help="cfg3 = the headline benchmark; newfluidnet = SURVEY 8(f) N1, the deployed multi-resolution trunk "
                         "(-net newfluidnet -l 5 -f 16 -r 6 -k 5) on its 128 x 506 grid")
@@ -141,9 +143,10 @@ def main():
     torch.manual_seed(0)                                   # identical initial weights on every rank
     if n1:
         from pbml_mantle_convection_amd.pytorch_networks_convae import NewFluidNet
-        model = NewFluidNet(5, 7, 16, 3, dev, "gelu", "zeros", "mass", use_symm=True, repeats=6, f=5, p_pred=True)
+        model = NewFluidNet(5, 7, 16, 4 if args.r_p == "learned" else 3, dev, "gelu", args.r_p or "zeros", "mass", use_symm=True,
+                            repeats=6, f=5, p_pred=True)
     else:
-        model = Unet(CFG["levels"], CFG["c_i"], CFG["c_h"], CFG["c_o"], dev, CFG["act"], CFG["r_p"], CFG["loss_type"],
+        model = Unet(CFG["levels"], CFG["c_i"], CFG["c_h"], CFG["c_o"], dev, CFG["act"], args.r_p or CFG["r_p"], CFG["loss_type"],
                      use_symm=CFG["use_symm"], repeats=CFG["repeats"], f=CFG["f"], p_pred=CFG["p_pred"])
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10 ** 9], gamma=0.5)
@@ -194,7 +197,7 @@ def main():
     torch.cuda.synchronize(dev)
     roof = eng.probe_summary(probe, HBM_PEAK_GBS)
     eng.disable_probe()
-    roof["traffic"] = pmc_traffic(roof["kernel"], B, H, W, args.precision)
+    roof["traffic"] = pmc_traffic(roof["kernel"], B, H, W, args.precision) if roof["kernel"] else None
 
     line = None
     if rank == 0:
@@ -207,10 +210,12 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": (f"N1: NewFluidNet (levels 5, c_h 16, k 5, repeats 6, zeros, symmetric) + scaled L1 data loss "
                                     f"+ divergence, {H}x{W}, per-GPU batch {B}, Adam, "
-                                    f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}") if n1 else
+                                    f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}"
+                                    + (f", r_p={args.r_p}" if args.r_p else "")) if n1 else
                                    f"CFG-3: symmetric U-Net (levels 5, c_h 16, k 5, repeats 3, reflect) + L1 data loss "
                                    f"+ divergence + Stokes momentum residual, {H}x{W}, per-GPU batch {B}, Adam, "
-                                   f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}",
+                                   f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}"
+                                   + (f", r_p={args.r_p}" if args.r_p else ""),
                        "global_batch": world * B, "grid": [H, W], "parallelism": f"dp{world}",
                        "loss": float(loss)},
             "roofline": roof,

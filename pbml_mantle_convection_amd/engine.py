@@ -892,6 +892,9 @@ class Engine:
             g["bytes"] += nbytes
             g["flops"] += flops
             g["n"] += 1
+        if not groups:                               # (a network of learned-padding layers only: no plain mc_conv2d node probed)
+            return {"bound": "hbm", "achieved": None, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": None, "launches": 0}
         name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
         ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": ach / hbm_peak_gbs,
@@ -906,6 +909,10 @@ class Engine:
         tot = 0
         for e in self.plan:
             if e["node"].kind != "conv":
+                continue
+            if e["node"].learned:
+                src, o = self.T[e["node"].srcs[0]], self.T[e["node"].out]
+                tot += src.C * src.H * src.W + o.C * o.H * o.W
                 continue
             d = e["desc"]
             ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
