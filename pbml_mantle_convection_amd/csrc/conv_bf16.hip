@@ -693,7 +693,8 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
   int nt_total = (g.Cout + 15) / 16;
   int groups = (nt_total + c.nt - 1) / c.nt;
   int items = g.tiles * g.N;
-  int cap = 4096 / groups > 0 ? 4096 / groups : 1;     // persistent: a few resident workgroups per CU, several items each
+  static int cap_total = getenv("MC_CONV_CAP") ? atoi(getenv("MC_CONV_CAP")) : 4096;   // (environment override: tuning runs only)
+  int cap = cap_total / groups > 0 ? cap_total / groups : 1;     // persistent: a few resident workgroups per CU, several items each
   int bx = items < cap ? items : cap;
   dim3 grid(bx, groups, 1);
 #define LAUNCH(K, TH, TW, NT, MT)                                                                                    \
