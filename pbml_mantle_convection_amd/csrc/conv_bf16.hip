@@ -440,31 +440,47 @@ constexpr int WTH = 16, WTW = 32;      // work-item tile (output pixels)
 #define MC_WGRAD_BATCH_NTW 1          // batch the tap-fragment reads of a row for NTW >= this (3 = never, 1 = always)
 #endif
 
-template <int K, int NTW>
+// RS ("register shift", NTW == 1 only): the K dimension of an MFMA is 4 rows x 8 pixels instead of 32 pixels of a
+// row, so the B fragments of the K taps of a filter row are windows [kx, kx+8) of the SAME 12 pixels of a lane: three
+// transposing reads + 8 v_alignbit feed 5 MFMAs (0.7 LDS reads per MFMA instead of 2.3; the kernel was LDS-issue
+// bound).  Every wave then owns a column block of the tile and ALL taps (26 accumulators); the four waves' sums are
+// combined through LDS once per workgroup.
+template <int K, int NTW, bool RS>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
                                                             const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
                                                             float* __restrict__ part, int tiles_x, int tiles) {
+  static_assert(!RS || NTW == 1, "register-shift variant holds all taps of one co-tile");
   constexpr int KK = K * K;
   constexpr int TIH = WTH + K - 1, TIW = WTW + K - 1;
-  constexpr int XPS = ((TIH * TIW + 15) / 16) * 16 + 4;       // x plane stride (slots), == 4 mod 16
-  constexpr int DPS = WTH * WTW + 4;                          // dy plane stride (slots)
+  // RS: row strides == 4 and plane strides == 8 (mod 16 slots) make the 4 row groups x 2 planes of a transposing read
+  // hit 8 distinct bank quads
+  constexpr int XRS = RS ? (TIW + 11) / 16 * 16 + 4 : TIW;    // x row stride (slots)
+  constexpr int DRS = RS ? WTW + 4 : WTW;                     // dy row stride (slots)
+  constexpr int XPS = RS ? (TIH * XRS + 15) / 16 * 16 + 8 : ((TIH * TIW + 15) / 16) * 16 + 4;   // x plane stride (slots)
+  constexpr int DPS = RS ? WTH * DRS + 8 : WTH * WTW + 4;     // dy plane stride (slots)
+  static_assert(!RS || (XRS >= TIW && XRS >= 3 * 8 + 12 && XRS % 16 == 4 && DRS % 16 == 4 && XPS % 16 == 8 && DPS % 16 == 8),
+                "register-shift LDS layout");
   constexpr int NTAP = (KK + 3) / 4;                          // taps per wave (upper bound)
+  constexpr int NACC = RS ? KK + 1 : NTAP * NTW;              // RS: every tap + the bias gradient
   constexpr int X_ELEMS = 2 * TIH * TIW, X_ITERS = (X_ELEMS + 255) / 256;
   constexpr int D_ELEMS = NTW * 2 * WTH * WTW, D_ITERS = D_ELEMS / 256;
   static_assert(D_ELEMS % 256 == 0, "dy tile must divide evenly over the threads");
-  __shared__ uint4 xs[2 * XPS];
-  __shared__ uint4 ds[NTW * 2 * DPS];
+  __shared__ uint4 smem[2 * XPS + NTW * 2 * DPS];
+  static_assert(!RS || sizeof(smem) >= NACC * 256 * sizeof(float), "cross-wave reduction reuses the tile buffers");
+  uint4* const xs = smem;
+  uint4* const ds = smem + 2 * XPS;
   const int chunk = blockIdx.y, cog = blockIdx.z;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tap offsets live in SGPRs
   const int q = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
   // per-lane short offsets (2-byte units) inside a plane pair for pixel 8g + q of a row start
-  const int lane_x = ((p >> 1) * XPS + 8 * gq + q) * 8 + (p & 1) * 4;
-  const int lane_d = ((p >> 1) * DPS + 8 * gq + q) * 8 + (p & 1) * 4;
+  // (RS: pixel q of row gq of the wave's 8-column block)
+  const int lane_x = RS ? ((p >> 1) * XPS + gq * XRS + 8 * wave + q) * 8 + (p & 1) * 4 : ((p >> 1) * XPS + 8 * gq + q) * 8 + (p & 1) * 4;
+  const int lane_d = RS ? ((p >> 1) * DPS + gq * DRS + 8 * wave + q) * 8 + (p & 1) * 4 : ((p >> 1) * DPS + 8 * gq + q) * 8 + (p & 1) * 4;
   const short* xs_s = reinterpret_cast<const short*>(xs);
   const short* ds_s = reinterpret_cast<const short*>(ds);
   static_assert(3 + 4 * (NTAP - 1) >= KK, "wave 3 needs a free accumulator slot for the bias gradient");
-  const bool do_bias = (wave == 3) && (chunk == 0);
+  const bool do_bias = (RS || wave == 3) && (chunk == 0);
   const bf16x8 ones = (bf16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const ptrdiff_t x1_delta = x1 ? reinterpret_cast<const char*>(x1) - reinterpret_cast<const char*>(x0) : (ptrdiff_t)0;
 
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     int r = rem / TIW, c = rem - r * TIW;
     x_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;
     x_off[it] = (unsigned)(r * g.W + c) * 16u;
-    x_lds[it] = live ? cb * XPS + r * TIW + c : -1;
+    x_lds[it] = live ? cb * XPS + r * XRS + c : -1;
   }
   // dy staging: static element offset of this thread's slots inside a (image, co-group) tile that lies fully inside
   unsigned d_off[D_ITERS];
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     int rem = i - pl * (WTH * WTW);
     int r = rem / WTW, c = rem - r * WTW;
     d_off[it] = (unsigned)((pl * g.Ho + r) * g.Wo + c) * 16u;
-    d_lds[it] = pl * DPS + rem;
+    d_lds[it] = pl * DPS + r * DRS + c;
   }
   const bool co_full = (cog * NTW + NTW) * 2 <= g.CBout;        // every co plane of this block exists
   // channel blocks of this (chunk): uniform
@@ -578,11 +594,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     for (int it = 0; it < D_ITERS; ++it) ds[d_lds[it]] = rd[it];
   };
 
-  f32x4 acc[NTAP][NTW];
+  f32x4 acc[NACC];                          // !RS: [tap slot][co tile]
 #pragma unroll
-  for (int a = 0; a < NTAP; ++a)
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < NACC; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int work = g.N * tiles;
   if (bid < work) prefetch(bid);
@@ -590,10 +604,44 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     __syncthreads();
     commit();
     __syncthreads();
+#ifndef MC_WEXP_NOLOAD   /* timing-only ablations (results wrong): MC_WEXP_NOLOAD, MC_WEXP_NOK */
     if (wi + (int)gridDim.x < work) prefetch(wi + gridDim.x);   // next work item's loads retire under the MFMA loop
+#endif
+#ifdef MC_WEXP_NOK
+    if (g.N > 1000000)
+#endif
 #ifndef MC_WGRAD_ROW_UNROLL
 #define MC_WGRAD_ROW_UNROLL 2   /* A/B on MI355X: 2 and 4 equal within noise, 16 thrashes the instruction cache (70x slower) */
 #endif
+    if constexpr (RS) {
+      typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int rg = 0; rg < WTH / 4; ++rg) {                    // K block = rows 4rg..4rg+3 x this wave's 8 columns
+        const short* dp = ds_s + lane_d + rg * 4 * DRS * 8;
+        const bf16x8 a = tr_frag(dp);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const short* xp = xs_s + lane_x + (rg * 4 + ky) * XRS * 8;
+          // 12 pixels of this lane's (row, channel) as 6 packed dwords
+          const u2 b0 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)xp));
+          const u2 b1 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(xp + 32)));
+          const u2 b2 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(xp + 64)));
+          const unsigned d[6] = {b0[0], b0[1], b1[0], b1[1], b2[0], b2[1]};
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            v4u w;
+            if (kx % 2 == 0) {
+              w = (v4u){d[kx / 2], d[kx / 2 + 1], d[kx / 2 + 2], d[kx / 2 + 3]};
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbit(d[kx / 2 + j + 1], d[kx / 2 + j], 16);
+            }
+            acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, w), acc[ky * K + kx], 0, 0, 0);
+          }
+        }
+        if (do_bias) acc[KK] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, acc[KK], 0, 0, 0);
+      }
+    } else {
     // rows unrolled so that the row offsets become instruction immediates (the loop was VALU-issue bound on address adds)
 #pragma unroll MC_WGRAD_ROW_UNROLL
     for (int row = 0; row < WTH; ++row) {
@@ -612,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
         for (int ti = 0; ti < NTAP; ++ti) {
           if (toff[ti] >= 0) {
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bq[ti], acc[ti][t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[ti * NTW + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bq[ti], acc[ti * NTW + t], 0, 0, 0);
           }
         }
       } else {
@@ -621,20 +669,53 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
           if (toff[ti] >= 0) {
             bf16x8 b = tr_frag(xtap[ti] + row * TIW * 8);
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[ti][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[ti][t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[ti * NTW + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[ti * NTW + t], 0, 0, 0);
           }
         }
       }
       if (do_bias) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-          acc[NTAP - 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], ones, acc[NTAP - 1][t], 0, 0, 0);
+          acc[(NTAP - 1) * NTW + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], ones, acc[(NTAP - 1) * NTW + t], 0, 0, 0);
       }
+    }
     }
   }
   // ---- write this block's partial slab: P[tap][chunk][co][16] (+ bias); a 16-lane group stores 64 contiguous bytes
   const int nch = wg_chunks(g.CinP);
   float* pb = part + (size_t)bid * wg_slab_floats(g.CoutP, g.CinP, KK);
+  if constexpr (RS) {
+    // waves 1..3 hand their accumulators to wave 0 through the (now idle) tile buffers, one wave per round
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    for (int src = 1; src < 4; ++src) {
+      __syncthreads();
+      if (wave == src) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) red[a * 64 + lane] = acc[a];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += red[a * 64 + lane];
+      }
+    }
+    if (wave != 0) return;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int co = cog * 16 + gq * 4 + r;
+        if (co < g.CoutP) pb[((size_t)(tap * nch + chunk) * g.CoutP + co) * 16 + (lane & 15)] = acc[tap][r];
+      }
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int co = cog * 16 + gq * 4 + r;
+        if (co < g.CoutP) pb[(size_t)KK * nch * g.CoutP * 16 + co] = acc[KK][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ti = 0; ti < NTAP; ++ti) {
     int tap = wave + 4 * ti;
@@ -645,9 +726,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
         int co = (cog * NTW + t) * 16 + gq * 4 + r;
         if (co >= g.CoutP) continue;
         if (tap < KK) {
-          pb[((size_t)(tap * nch + chunk) * g.CoutP + co) * 16 + (lane & 15)] = acc[ti][t][r];
+          pb[((size_t)(tap * nch + chunk) * g.CoutP + co) * 16 + (lane & 15)] = acc[ti * NTW + t][r];
         } else if (do_bias && ti == NTAP - 1 && (lane & 15) == 0) {
-          pb[(size_t)KK * nch * g.CoutP * 16 + co] = acc[ti][t][r];
+          pb[(size_t)KK * nch * g.CoutP * 16 + co] = acc[ti * NTW + t][r];
         }
       }
   }
@@ -741,11 +822,12 @@ int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void*
   const int ntiles = (g.Cout + 15) / 16;
   const int ntw = pick_nt(ntiles) >= 2 ? 2 : 1;      // two co-tiles per block keep LDS at 55 KB (2-3 blocks per CU)
   dim3 grid(g.wgrad_G, (g.CBin + 1) / 2, (ntiles + ntw - 1) / ntw);
-#define WLAUNCH(K, NTW)                                                                                              \
-  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1,     \
+#define WLAUNCH(K, NTW, RS)                                                                                          \
+  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW, RS>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, \
                      (const bf16_t*)dy, (float*)part, tiles_x, tiles)
-  if (g.K == 5) { if (ntw == 1) WLAUNCH(5, 1); else WLAUNCH(5, 2); }
-  else if (g.K == 3) { if (ntw == 1) WLAUNCH(3, 1); else WLAUNCH(3, 2); }
+  static const bool rs = [] { const char* e = getenv("MC_WGRAD_RS"); return e ? atoi(e) != 0 : true; }();   // A/B knob
+  if (g.K == 5) { if (ntw == 1) { if (rs) WLAUNCH(5, 1, true); else WLAUNCH(5, 1, false); } else WLAUNCH(5, 2, false); }
+  else if (g.K == 3) { if (ntw == 1) { if (rs) WLAUNCH(3, 1, true); else WLAUNCH(3, 1, false); } else WLAUNCH(3, 2, false); }
   else return MC_EUNSUPPORTED;
 #undef WLAUNCH
   MC_CHECK_LAUNCH();
