@@ -440,16 +440,21 @@ constexpr int WTH = 16, WTW = 32;      // work-item tile (output pixels)
 #define MC_WGRAD_BATCH_NTW 1          // batch the tap-fragment reads of a row for NTW >= this (3 = never, 1 = always)
 #endif
 
-// RS ("register shift", NTW == 1 only): the K dimension of an MFMA is 4 rows x 8 pixels instead of 32 pixels of a
-// row, so the B fragments of the K taps of a filter row are windows [kx, kx+8) of the SAME 12 pixels of a lane: three
-// transposing reads + 8 v_alignbit feed 5 MFMAs (0.7 LDS reads per MFMA instead of 2.3; the kernel was LDS-issue
-// bound).  Every wave then owns a column block of the tile and ALL taps (26 accumulators); the four waves' sums are
-// combined through LDS once per workgroup.
-template <int K, int NTW, bool RS>
-__global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
+// RS ("register shift", RS != 0): the K dimension of an MFMA is 4 rows x 8 pixels instead of 32 pixels of a row, so
+// the B fragments of the K taps of a filter row are windows [kx, kx+8) of the SAME 12 pixels of a lane: three
+// transposing reads + 8 v_alignbit feed 5 MFMAs (0.7-0.85 LDS reads per MFMA instead of 2.3; the kernel was LDS-issue
+// bound).  RS = number of tap groups the 25 taps are split into: wave = (tap group tg = wave % RS, column group
+// wave / RS of RS 8-column blocks).  RS 1: all taps + bias, one column block (26 NTW accumulators); RS 2: 13/12 taps,
+// two column blocks; RS 4: 7/6/6/6 taps, the whole tile (no cross-wave sum).  The bias gradient rides in the spare
+// slot of the last tap group.  Column groups are summed through LDS once per workgroup.
+template <int K, int NTW, int RS>
+__global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
                                                             const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
                                                             float* __restrict__ part, int tiles_x, int tiles) {
-  static_assert(!RS || NTW == 1, "register-shift variant holds all taps of one co-tile");
+  static_assert(RS == 0 || RS == 1 || RS == 2 || RS == 4, "tap groups");
+  constexpr int NS = RS ? RS : 1;                               // tap groups
+  constexpr int NG = 4 / NS;                                    // column groups (waves that share a tap group)
+  constexpr int TPW = (K * K + NS) / NS;                        // accumulator slots of a wave (last group: + bias)
   constexpr int KK = K * K;
   constexpr int TIH = WTH + K - 1, TIW = WTW + K - 1;
   // RS: row strides == 4 and plane strides == 8 (mod 16 slots) make the 4 row groups x 2 planes of a transposing read
@@ -461,12 +466,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   static_assert(!RS || (XRS >= TIW && XRS >= 3 * 8 + 12 && XRS % 16 == 4 && DRS % 16 == 4 && XPS % 16 == 8 && DPS % 16 == 8),
                 "register-shift LDS layout");
   constexpr int NTAP = (KK + 3) / 4;                          // taps per wave (upper bound)
-  constexpr int NACC = RS ? KK + 1 : NTAP * NTW;              // RS: every tap + the bias gradient
+  constexpr int NACC = RS ? TPW * NTW : NTAP * NTW;            // [tap slot (+ bias)][co tile]
   constexpr int X_ELEMS = 2 * TIH * TIW, X_ITERS = (X_ELEMS + 255) / 256;
   constexpr int D_ELEMS = NTW * 2 * WTH * WTW, D_ITERS = D_ELEMS / 256;
   static_assert(D_ELEMS % 256 == 0, "dy tile must divide evenly over the threads");
   __shared__ uint4 smem[2 * XPS + NTW * 2 * DPS];
-  static_assert(!RS || sizeof(smem) >= NACC * 256 * sizeof(float), "cross-wave reduction reuses the tile buffers");
+  static_assert(RS == 0 || RS == 4 || sizeof(smem) >= NS * NACC * 256 * sizeof(float), "cross-wave reduction reuses the tile buffers");
   uint4* const xs = smem;
   uint4* const ds = smem + 2 * XPS;
   const int chunk = blockIdx.y, cog = blockIdx.z;
@@ -474,13 +479,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tap offsets live in SGPRs
   const int q = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
   // per-lane short offsets (2-byte units) inside a plane pair for pixel 8g + q of a row start
-  // (RS: pixel q of row gq of the wave's 8-column block)
-  const int lane_x = RS ? ((p >> 1) * XPS + gq * XRS + 8 * wave + q) * 8 + (p & 1) * 4 : ((p >> 1) * XPS + 8 * gq + q) * 8 + (p & 1) * 4;
-  const int lane_d = RS ? ((p >> 1) * DPS + gq * DRS + 8 * wave + q) * 8 + (p & 1) * 4 : ((p >> 1) * DPS + 8 * gq + q) * 8 + (p & 1) * 4;
+  // (RS: pixel q of row gq of the wave's first 8-column block)
+  const int tg = wave % NS, cg = wave / NS;
+  const int col0 = 8 * NS * cg;
+  const int lane_x = RS ? ((p >> 1) * XPS + gq * XRS + col0 + q) * 8 + (p & 1) * 4 : ((p >> 1) * XPS + 8 * gq + q) * 8 + (p & 1) * 4;
+  const int lane_d = RS ? ((p >> 1) * DPS + gq * DRS + col0 + q) * 8 + (p & 1) * 4 : ((p >> 1) * DPS + 8 * gq + q) * 8 + (p & 1) * 4;
   const short* xs_s = reinterpret_cast<const short*>(xs);
   const short* ds_s = reinterpret_cast<const short*>(ds);
   static_assert(3 + 4 * (NTAP - 1) >= KK, "wave 3 needs a free accumulator slot for the bias gradient");
-  const bool do_bias = (RS || wave == 3) && (chunk == 0);
+  const bool do_bias = (RS == 0 ? wave == 3 : tg == NS - 1) && (chunk == 0);
   const bf16x8 ones = (bf16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const ptrdiff_t x1_delta = x1 ? reinterpret_cast<const char*>(x1) - reinterpret_cast<const char*>(x0) : (ptrdiff_t)0;
 
@@ -497,7 +504,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   // static staging slots of this thread (decoded once: the staging address arithmetic was a third of the kernel's VALU work)
   int x_rc[X_ITERS];
   unsigned x_off[X_ITERS];
-  int x_lds[X_ITERS];
 #pragma unroll
   for (int it = 0; it < X_ITERS; ++it) {
     int i = threadIdx.x + it * 256;
@@ -508,20 +514,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     int r = rem / TIW, c = rem - r * TIW;
     x_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;
     x_off[it] = (unsigned)(r * g.W + c) * 16u;
-    x_lds[it] = live ? cb * XPS + r * XRS + c : -1;
   }
   // dy staging: static element offset of this thread's slots inside a (image, co-group) tile that lies fully inside
-  unsigned d_off[D_ITERS];
-  int d_lds[D_ITERS];
-#pragma unroll
-  for (int it = 0; it < D_ITERS; ++it) {
-    int i = threadIdx.x + it * 256;
-    int pl = i / (WTH * WTW);
-    int rem = i - pl * (WTH * WTW);
-    int r = rem / WTW, c = rem - r * WTW;
-    d_off[it] = (unsigned)((pl * g.Ho + r) * g.Wo + c) * 16u;
-    d_lds[it] = pl * DPS + r * DRS + c;
-  }
+  // (256 threads = 8 rows x 32 columns; slot `it` of a thread is plane it / 2, row + 8 (it & 1): one VGPR offset, the
+  // rest is uniform or an immediate)
+  static_assert(WTW == 32 && WTH == 16, "dy staging decode");
+  const int d_r0 = threadIdx.x >> 5, d_c0 = threadIdx.x & 31;
+  const unsigned d_off0 = (unsigned)(d_r0 * g.Wo + d_c0) * 16u;
+  const int d_lds0 = d_r0 * DRS + d_c0;
   const bool co_full = (cog * NTW + NTW) * 2 <= g.CBout;        // every co plane of this block exists
   // channel blocks of this (chunk): uniform
   const char* xbase[2];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
   }
 
   uint4 rx[X_ITERS], rd[D_ITERS];
-  auto prefetch = [&](int wi) {
+  auto prefetch = [&](int wi) __attribute__((always_inline)) {
     const int n = wi / tiles, tile = wi - n * tiles;
     const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     if (co_full && ty0 + WTH <= g.Ho && tx0 + WTW <= g.Wo) {
       const char* db = reinterpret_cast<const char*>(dy) + cb8_index(n, cog * NTW * 2, ty0, tx0, g.CBout, g.Ho, g.Wo) * sizeof(bf16_t);
 #pragma unroll
-      for (int it = 0; it < D_ITERS; ++it) rd[it] = *reinterpret_cast<const uint4*>(db + d_off[it]);
+      for (int it = 0; it < D_ITERS; ++it)
+        rd[it] = *reinterpret_cast<const uint4*>(db + (size_t)((it >> 1) * g.Ho + 8 * (it & 1)) * g.Wo * 16 + d_off0);
       return;
     }
 #pragma unroll
@@ -586,12 +587,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
       rd[it] = ok ? v : make_uint4(0, 0, 0, 0);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < X_ITERS; ++it)
-      if (x_lds[it] >= 0) xs[x_lds[it]] = rx[it];
+    {
+      int v = x_rc[it];
+      asm volatile("" : "+v"(v));               // opaque: keeps the slot decode out of loop-invariant registers
+      if (v >= 0) xs[((v >> 30) & 1) * XPS + ((v >> 15) & 0x7fff) * XRS + (v & 0x7fff)] = rx[it];
+    }
 #pragma unroll
-    for (int it = 0; it < D_ITERS; ++it) ds[d_lds[it]] = rd[it];
+    for (int it = 0; it < D_ITERS; ++it) ds[d_lds0 + (it >> 1) * DPS + 8 * (it & 1) * DRS] = rd[it];
   };
 
   f32x4 acc[NACC];                          // !RS: [tap slot][co tile]
@@ -600,6 +605,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
 
   const int work = g.N * tiles;
   if (bid < work) prefetch(bid);
+  // The tap group of a wave is wave-uniform; the whole tile loop is instantiated per group (tg_c) and the branch sits
+  // OUTSIDE it: with the branch inside, the two arms' accumulators were allocated to disjoint registers (+52 VGPRs).
+  // Every arm executes the same sequence of workgroup barriers.
+  auto tile_loop = [&](auto tg_c) __attribute__((always_inline)) {
   for (int wi = bid; wi < work; wi += gridDim.x) {
     __syncthreads();
     commit();
@@ -613,34 +622,59 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
 #ifndef MC_WGRAD_ROW_UNROLL
 #define MC_WGRAD_ROW_UNROLL 2   /* A/B on MI355X: 2 and 4 equal within noise, 16 thrashes the instruction cache (70x slower) */
 #endif
-    if constexpr (RS) {
+    if constexpr (RS != 0) {
       typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+      // TG is a compile-time copy of the wave-uniform tap group so that the accumulators stay statically indexed
+      auto body = [&](auto tg_c) __attribute__((always_inline)) {
+        constexpr int TG = decltype(tg_c)::value;
+        constexpr int T0 = TG == 0 ? 0 : TPW + (TG - 1) * (TPW - 1);
+        constexpr int T1 = (TPW + TG * (TPW - 1)) < KK ? (TPW + TG * (TPW - 1)) : KK;
+        static_assert(TG < NS - 1 || (T1 == KK && T1 - T0 < TPW), "the last tap group ends the filter and has a spare slot");
 #pragma unroll
-      for (int rg = 0; rg < WTH / 4; ++rg) {                    // K block = rows 4rg..4rg+3 x this wave's 8 columns
-        const short* dp = ds_s + lane_d + rg * 4 * DRS * 8;
-        const bf16x8 a = tr_frag(dp);
+        for (int rg = 0; rg < WTH / 4; ++rg) {                  // K block = rows 4rg..4rg+3 x an 8-column block
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-          const short* xp = xs_s + lane_x + (rg * 4 + ky) * XRS * 8;
-          // 12 pixels of this lane's (row, channel) as 6 packed dwords
-          const u2 b0 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)xp));
-          const u2 b1 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(xp + 32)));
-          const u2 b2 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(xp + 64)));
-          const unsigned d[6] = {b0[0], b0[1], b1[0], b1[1], b2[0], b2[1]};
+          for (int cb = 0; cb < NS; ++cb) {
+            const short* dp = ds_s + lane_d + (rg * 4 * DRS + cb * 8) * 8;
+            bf16x8 a[NTW];
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            v4u w;
-            if (kx % 2 == 0) {
-              w = (v4u){d[kx / 2], d[kx / 2 + 1], d[kx / 2 + 2], d[kx / 2 + 3]};
-            } else {
+            for (int t = 0; t < NTW; ++t) a[t] = tr_frag(dp + t * 2 * DPS * 8);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbit(d[kx / 2 + j + 1], d[kx / 2 + j], 16);
+            for (int ky = 0; ky < K; ++ky) {
+              if (ky * K + K <= T0 || ky * K >= T1) continue;   // no tap of this filter row belongs to the wave
+              const short* xp = xs_s + lane_x + ((rg * 4 + ky) * XRS + cb * 8) * 8;
+              // 12 pixels of this lane's (row, channel) as 6 packed dwords
+              const u2 b0 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)xp));
+              const u2 b1 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(xp + 32)));
+              const u2 b2 = __builtin_bit_cast(u2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(xp + 64)));
+              const unsigned d[6] = {b0[0], b0[1], b1[0], b1[1], b2[0], b2[1]};
+#pragma unroll
+              for (int kx = 0; kx < K; ++kx) {
+                const int tap = ky * K + kx;
+                if (tap < T0 || tap >= T1) continue;
+                v4u w;
+                if (kx % 2 == 0) {
+                  w = (v4u){d[kx / 2], d[kx / 2 + 1], d[kx / 2 + 2], d[kx / 2 + 3]};
+                } else {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbit(d[kx / 2 + j + 1], d[kx / 2 + j], 16);
+                }
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                  acc[(tap - T0) * NTW + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], __builtin_bit_cast(bf16x8, w), acc[(tap - T0) * NTW + t], 0, 0, 0);
+              }
             }
-            acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, w), acc[ky * K + kx], 0, 0, 0);
+            if (TG == NS - 1 && do_bias) {
+#pragma unroll
+              for (int t = 0; t < NTW; ++t)
+                acc[(TPW - 1) * NTW + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], ones, acc[(TPW - 1) * NTW + t], 0, 0, 0);
+            }
+#ifndef MC_WGRAD_NOFENCE
+            if constexpr (NS > 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every block's reads (spills)
+#endif
           }
         }
-        if (do_bias) acc[KK] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, acc[KK], 0, 0, 0);
-      }
+      };
+      body(tg_c);
     } else {
     // rows unrolled so that the row offsets become instruction immediates (the loop was VALU-issue bound on address adds)
 #pragma unroll MC_WGRAD_ROW_UNROLL
@@ -681,38 +715,51 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf
     }
     }
   }
+  };
+  if constexpr (NS == 1) tile_loop(std::integral_constant<int, 0>{});
+  else if constexpr (NS == 2) { if (tg == 0) tile_loop(std::integral_constant<int, 0>{}); else tile_loop(std::integral_constant<int, 1>{}); }
+  else {
+    if (tg == 0) tile_loop(std::integral_constant<int, 0>{}); else if (tg == 1) tile_loop(std::integral_constant<int, 1>{});
+    else if (tg == 2) tile_loop(std::integral_constant<int, 2>{}); else tile_loop(std::integral_constant<int, 3>{});
+  }
   // ---- write this block's partial slab: P[tap][chunk][co][16] (+ bias); a 16-lane group stores 64 contiguous bytes
   const int nch = wg_chunks(g.CinP);
   float* pb = part + (size_t)bid * wg_slab_floats(g.CoutP, g.CinP, KK);
-  if constexpr (RS) {
-    // waves 1..3 hand their accumulators to wave 0 through the (now idle) tile buffers, one wave per round
+  if constexpr (RS != 0) {
+    // column groups 1.. hand their accumulators to group 0 through the (now idle) tile buffers, one group per round
     f32x4* red = reinterpret_cast<f32x4*>(smem);
-    for (int src = 1; src < 4; ++src) {
+    for (int src = 1; src < NG; ++src) {
       __syncthreads();
-      if (wave == src) {
+      if (cg == src) {
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) red[a * 64 + lane] = acc[a];
+        for (int a = 0; a < NACC; ++a) red[(tg * NACC + a) * 64 + lane] = acc[a];
       }
       __syncthreads();
-      if (wave == 0) {
+      if (cg == 0) {
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += red[a * 64 + lane];
+        for (int a = 0; a < NACC; ++a) acc[a] += red[(tg * NACC + a) * 64 + lane];
       }
     }
-    if (wave != 0) return;
+    if (cg != 0) return;
+    const int t0 = tg == 0 ? 0 : TPW + (tg - 1) * (TPW - 1);
+    const int nt = min(KK, TPW + tg * (TPW - 1)) - t0;
 #pragma unroll
-    for (int tap = 0; tap < KK; ++tap)
+    for (int sl = 0; sl < TPW; ++sl)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int co = cog * 16 + gq * 4 + r;
-        if (co < g.CoutP) pb[((size_t)(tap * nch + chunk) * g.CoutP + co) * 16 + (lane & 15)] = acc[tap][r];
-      }
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int co = (cog * NTW + t) * 16 + gq * 4 + r;
+          if (sl < nt && co < g.CoutP) pb[((size_t)((t0 + sl) * nch + chunk) * g.CoutP + co) * 16 + (lane & 15)] = acc[sl * NTW + t][r];
+        }
     if (do_bias && (lane & 15) == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int co = cog * 16 + gq * 4 + r;
-        if (co < g.CoutP) pb[(size_t)KK * nch * g.CoutP * 16 + co] = acc[KK][r];
-      }
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int co = (cog * NTW + t) * 16 + gq * 4 + r;
+          if (co < g.CoutP) pb[(size_t)KK * nch * g.CoutP * 16 + co] = acc[(TPW - 1) * NTW + t][r];
+        }
     }
     return;
   }
@@ -825,10 +872,16 @@ int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void*
 #define WLAUNCH(K, NTW, RS)                                                                                          \
   hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW, RS>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, \
                      (const bf16_t*)dy, (float*)part, tiles_x, tiles)
-  static const bool rs = [] { const char* e = getenv("MC_WGRAD_RS"); return e ? atoi(e) != 0 : true; }();   // A/B knob
-  if (g.K == 5) { if (ntw == 1) { if (rs) WLAUNCH(5, 1, true); else WLAUNCH(5, 1, false); } else WLAUNCH(5, 2, false); }
-  else if (g.K == 3) { if (ntw == 1) { if (rs) WLAUNCH(3, 1, true); else WLAUNCH(3, 1, false); } else WLAUNCH(3, 2, false); }
+  // A/B knob: two decimal digits = tap groups for (one co-tile, two co-tiles); 0 = the row-at-a-time kernel.  Measured
+  // alone at level 0 (16->16, 32x506x512): 0: 266 us, 1: 171, 2: 203, 4: 155; 64->64 at 63x64: 0: 44 us, 4: 37.  Inside
+  // the training step 10 / 14 / 44 are equal (the filter gradients run on the side stream and are off the critical path).
+  static const int rs = [] { const char* e = getenv("MC_WGRAD_RS"); return e ? atoi(e) : 44; }();
+  const int v = ntw == 1 ? rs / 10 : rs % 10;
+#define WPICK(K, NTW) do { if (v == 4) WLAUNCH(K, NTW, 4); else if (v == 2) WLAUNCH(K, NTW, 2); else if (v == 1 && NTW == 1) WLAUNCH(K, 1, 1); else WLAUNCH(K, NTW, 0); } while (0)
+  if (g.K == 5) { if (ntw == 1) WPICK(5, 1); else WPICK(5, 2); }
+  else if (g.K == 3) { if (ntw == 1) WPICK(3, 1); else WPICK(3, 2); }
   else return MC_EUNSUPPORTED;
+#undef WPICK
 #undef WLAUNCH
   MC_CHECK_LAUNCH();
   return MC_OK;
