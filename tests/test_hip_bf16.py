@@ -6,6 +6,8 @@ gradients: relative L2 error <= 6e-2; losses: relative 2e-2.
 End-to-end against the fp64 golden vectors the bounds are the bf16 noise floor of these random-weight test nets
 (12 % on fields that pass through the curl head's finite differences, 45 % relative L2 on the worst gradient); the tight
 checks are the per-kernel tests (1 %) and the quantisation-emulating oracle (1.5 %)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -66,6 +68,20 @@ def test_bf16_conv_forward_and_filter_gradient(ci, co, k, mode, h, hw):
     (ref * bf16_round(ct)).sum().backward()
     assert rel_l2(mm.weight.grad, w64.grad) < 1e-2
     assert rel_l2(mm.bias.grad, b64.grad) < 1e-2
+
+
+@pytest.mark.parametrize("variant", ["0", "12", "21"])
+def test_filter_gradient_kernel_variants(variant):
+    """The filter-gradient kernel has tap-group variants (MC_WGRAD_RS: tens digit = one co-tile, units = two co-tiles;
+    default 44).  The knob is read once per process, so the non-default forms run the conv cases in a child process:
+    0 = row-at-a-time kernel, 1 / 2 = register-shift kernel with one / two tap groups."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MC_WGRAD_RS=variant)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_bf16_conv_forward_and_filter_gradient"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "9 passed" in r.stdout, r.stdout[-500:]
 
 
 @pytest.mark.parametrize("tag", ["curl", "mae", "mass_rep", "mae_zeros"])
