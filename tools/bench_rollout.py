@@ -21,9 +21,12 @@ for prec in ("fp32", "bf16"):
         ts = TS(m, ADNet(dev), dev, ts=20, net="newfluidnet", use_graph=use_graph)
         ts(T0, None, None, yc, nd[0], nd[1], nd[2], raq, fkt, fkp, xc, yc)        # warm-up / capture
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        x, dts, *_ = ts(T0, None, None, yc, nd[0], nd[1], nd[2], raq, fkt, fkp, xc, yc)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 20 * 1e3
+        best = []
+        for _ in range(5):                      # the first replays of a fresh graph pay its upload: report the median
+            t0 = time.perf_counter()
+            x, dts, *_ = ts(T0, None, None, yc, nd[0], nd[1], nd[2], raq, fkt, fkp, xc, yc)
+            torch.cuda.synchronize()
+            best.append((time.perf_counter() - t0) / 20 * 1e3)
+        ms = sorted(best)[len(best) // 2]
         print(f"{prec} {'HIP graph' if use_graph else 'eager    '}: {ms:.3f} ms per rollout step (batch 1, 128x506), T range "
               f"[{float(x[20].min()):.3f}, {float(x[20].max()):.3f}]")
