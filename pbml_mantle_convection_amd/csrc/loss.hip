@@ -1,6 +1,7 @@
 // Fused loss forward + backward (Trainer.loss_fn / get_loss, reference multigpu.py:122-134, 250-305)
 // and the build-defined Stokes momentum residual.  5-point stencil work on
 // [N][H][W] f32 fields: tiny next to the network, so neighbours are simply re-read through L1/L2.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -99,8 +100,10 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
   const float sp = p_scaled ? fminf(fmaxf(1.0f / (mm[(n * 3 + 2) * 2 + 1] - mm[(n * 3 + 2) * 2 + 0]), 1.0f), 10.0f) : 1.f;
   const float cdu = 126.0f / (k * (float)g.d.n * (float)(H - 2) * (float)W);
   const float cdv = 126.0f / (k * (float)g.d.n * (float)H * (float)(W - 2));
-  double a_us = 0, a_up = 0, a_vs = 0, a_vp = 0, a_pp = 0, a_tp = 0, a_du = 0, a_dv = 0;
-  double a_m = 0, a_mx0 = 0, a_mx1 = 0, a_my0 = 0, a_my1 = 0;
+  // per-thread partial sums in f32 (a thread adds <= a few dozen pixels: relative rounding < 1e-5 of ITS share; the
+  // combination across threads, blocks and samples is f64): f64 adds were a third of this kernel's issue cycles
+  float a_us = 0, a_up = 0, a_vs = 0, a_vp = 0, a_pp = 0, a_tp = 0, a_du = 0, a_dv = 0;
+  float a_m = 0, a_mx0 = 0, a_mx1 = 0, a_my0 = 0, a_my1 = 0;
 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
     const int y = i / W, x = i % W;
@@ -115,16 +118,16 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
         a_tp += fabsf(dT);
         gu -= sgn(du) * wu * cdat; gv -= sgn(dv) * wv * cdat; gT -= sgn(dT) * cdat;
       } else {
-        a_us += (double)(du * wu) * (du * wu); a_up += (double)du * du;
-        a_vs += (double)(dv * wv) * (dv * wv); a_vp += (double)dv * dv;
-        a_tp += (double)dT * dT;
+        a_us += (du * wu) * (du * wu); a_up += du * du;
+        a_vs += (dv * wv) * (dv * wv); a_vp += dv * dv;
+        a_tp += dT * dT;
         gu -= 2.f * du * wu * wu * cdat; gv -= 2.f * dv * wv * wv * cdat; gT -= 2.f * dT * cdat;
       }
       if (p) {
         float dp = pt[i] - p[i];
         const float wp = p_scaled ? sp * bw : 1.f;
         if (!g.d.l2) { a_pp += fabsf(dp * wp); gp -= sgn(dp) * wp * cdat; }
-        else { a_pp += (double)(dp * wp) * (dp * wp); gp -= 2.f * dp * wp * wp * cdat; }
+        else { a_pp += (dp * wp) * (dp * wp); gp -= 2.f * dp * wp * wp * cdat; }
       }
     }
     if (g.d.loss_derivative) {
@@ -194,6 +197,9 @@ struct MomField {
     if (i < 0 || i > H - 2 || j < 0 || j >= W) return 0.f;
     return 0.5f * (eta(i, j) + eta(i + 1, j));
   }
+  // the same faces where the caller knows they lie inside the domain
+  __device__ __forceinline__ float exf_in(int i, int j) const { return 0.5f * (eta(i, j) + eta(i, j + 1)); }
+  __device__ __forceinline__ float eyf_in(int i, int j) const { return 0.5f * (eta(i, j) + eta(i + 1, j)); }
 };
 
 // eta = clip(exp(-ln(FKT) T + ln(FKP) (1 - y)), 1e-8, 1): one exp per pixel instead of ~20 per residual evaluation
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
   MomField f{eta_ + (size_t)n * HW, H, W};
   const float s = scaler[n], ih = g.ih;
   const float c = g.lam / ((float)g.N * (float)(H - 2) * (float)(W - 2));
-  double ax = 0, ay = 0;
+  float ax = 0, ay = 0;      // per-thread f32 partials (see k_loss)
   auto U = [&](int i, int j) { return s * u[(size_t)i * W + j]; };
   auto V = [&](int i, int j) { return s * v[(size_t)i * W + j]; };
   auto P = [&](int i, int j) { return p ? p[(size_t)i * W + j] : 0.f; };
@@ -231,15 +237,15 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
     const int i = idx / W, j = idx % W;
     float ox = 0.f, oy = 0.f;
     if (i >= 1 && i <= H - 2 && j >= 1 && j <= W - 2) {
-      float Fx1 = 2.f * f.exf(i, j) * (U(i, j + 1) - U(i, j)) * ih;
-      float Fx0 = 2.f * f.exf(i, j - 1) * (U(i, j) - U(i, j - 1)) * ih;
-      float Ty1 = f.eyf(i, j) * ((U(i + 1, j) - U(i, j)) * ih + 0.5f * (dVdx(i, j) + dVdx(i + 1, j)));
-      float Ty0 = f.eyf(i - 1, j) * ((U(i, j) - U(i - 1, j)) * ih + 0.5f * (dVdx(i - 1, j) + dVdx(i, j)));
+      float Fx1 = 2.f * f.exf_in(i, j) * (U(i, j + 1) - U(i, j)) * ih;
+      float Fx0 = 2.f * f.exf_in(i, j - 1) * (U(i, j) - U(i, j - 1)) * ih;
+      float Ty1 = f.eyf_in(i, j) * ((U(i + 1, j) - U(i, j)) * ih + 0.5f * (dVdx(i, j) + dVdx(i + 1, j)));
+      float Ty0 = f.eyf_in(i - 1, j) * ((U(i, j) - U(i - 1, j)) * ih + 0.5f * (dVdx(i - 1, j) + dVdx(i, j)));
       float Rx = -0.5f * (P(i, j + 1) - P(i, j - 1)) * ih + (Fx1 - Fx0) * ih + (Ty1 - Ty0) * ih;
-      float Fy1 = 2.f * f.eyf(i, j) * (V(i + 1, j) - V(i, j)) * ih;
-      float Fy0 = 2.f * f.eyf(i - 1, j) * (V(i, j) - V(i - 1, j)) * ih;
-      float Tx1 = f.exf(i, j) * ((V(i, j + 1) - V(i, j)) * ih + 0.5f * (dUdy(i, j) + dUdy(i, j + 1)));
-      float Tx0 = f.exf(i, j - 1) * ((V(i, j) - V(i, j - 1)) * ih + 0.5f * (dUdy(i, j - 1) + dUdy(i, j)));
+      float Fy1 = 2.f * f.eyf_in(i, j) * (V(i + 1, j) - V(i, j)) * ih;
+      float Fy0 = 2.f * f.eyf_in(i - 1, j) * (V(i, j) - V(i - 1, j)) * ih;
+      float Tx1 = f.exf_in(i, j) * ((V(i, j + 1) - V(i, j)) * ih + 0.5f * (dUdy(i, j) + dUdy(i, j + 1)));
+      float Tx0 = f.exf_in(i, j - 1) * ((V(i, j) - V(i, j - 1)) * ih + 0.5f * (dUdy(i, j - 1) + dUdy(i, j)));
       float Ry = -0.5f * (P(i + 1, j) - P(i - 1, j)) * ih + (Fy1 - Fy0) * ih + (Tx1 - Tx0) * ih + g.ra * T[idx];
       ax += fabsf(Rx); ay += fabsf(Ry);
       ox = c * sgn(Rx); oy = c * sgn(Ry);
@@ -253,39 +259,61 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
   bs.flush<2>(sums, slots);
 }
 
-__global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ T_, const float* __restrict__ eta_,
-                                                     const float* __restrict__ paras, const float* __restrict__ scaler,
+// Adjoint of the residual stencils, LDS-tiled: an 8 x 64 pixel tile with a one-pixel halo of S_x, S_y and eta is
+// staged once (zero outside the domain) and every face quantity is formed from LDS.  No domain masks are needed:
+// S is zero on the outermost ring and beyond (k_mom_residual writes 0 there), so every difference of S that an
+// out-of-domain face would multiply is itself zero, and the zero-filled eta keeps those faces finite.
+// (The straight per-pixel form issued ~40 bounds-checked global loads per pixel: 235 us at 32 x 506 x 506.)
+constexpr int MA_TH = 8, MA_TW = 64, MA_LW = MA_TW + 2, MA_LH = MA_TH + 2;
+__global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ eta_,
+                                                     const float* __restrict__ scaler,
                                                      const float* __restrict__ sx_, const float* __restrict__ sy_,
                                                      float* __restrict__ gu_, float* __restrict__ gv_,
-                                                     float* __restrict__ gp_, float* __restrict__ gT_, int t_grad) {
+                                                     float* __restrict__ gp_, float* __restrict__ gT_, int t_grad, int tiles_x) {
   const int H = g.H, W = g.W, HW = H * W, n = blockIdx.y;
-  const float* T = T_ + (size_t)n * g.pbs;
+  const int i0 = (blockIdx.x / tiles_x) * MA_TH, j0 = (blockIdx.x % tiles_x) * MA_TW;
   const float* sx = sx_ + (size_t)n * HW;
   const float* sy = sy_ + (size_t)n * HW;
-  MomField f{eta_ + (size_t)n * HW, H, W};
+  const float* et = eta_ + (size_t)n * HW;
+  __shared__ float sxs[MA_LH * MA_LW], sys[MA_LH * MA_LW], ets[MA_LH * MA_LW];
+  for (int t = threadIdx.x; t < MA_LH * MA_LW; t += 256) {
+    const int li = t / MA_LW, lj = t - li * MA_LW, i = i0 + li - 1, j = j0 + lj - 1;
+    const bool in = i >= 0 && i < H && j >= 0 && j < W;
+    const size_t o = in ? (size_t)i * W + j : 0;
+    sxs[t] = in ? sx[o] : 0.f;
+    sys[t] = in ? sy[o] : 0.f;
+    ets[t] = in ? et[o] : 0.f;
+  }
+  __syncthreads();
   const float s = scaler[n], ih = g.ih;
-  auto SX = [&](int i, int j) { return (i < 0 || i >= H || j < 0 || j >= W) ? 0.f : sx[(size_t)i * W + j]; };
-  auto SY = [&](int i, int j) { return (i < 0 || i >= H || j < 0 || j >= W) ? 0.f : sy[(size_t)i * W + j]; };
-  // adjoint face quantities (zero outside their domains because S is zero-extended)
-  auto dFx = [&](int i, int j) { return ih * (SX(i, j) - SX(i, j + 1)); };
-  auto dTy = [&](int i, int j) { return ih * (SX(i, j) - SX(i + 1, j)); };
-  auto dFy = [&](int i, int j) { return ih * (SY(i, j) - SY(i + 1, j)); };
-  auto dTx = [&](int i, int j) { return ih * (SY(i, j) - SY(i, j + 1)); };
-  auto E = [&](int i, int j) { return f.eyf(i, j) * dTy(i, j); };   // eyf = 0 outside the y-face domain
-  auto Fh = [&](int i, int j) { return f.exf(i, j) * dTx(i, j); };
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += gridDim.x * blockDim.x) {
-    const int i = idx / W, j = idx % W;
-    float dU = 2.f * ih * (f.exf(i, j - 1) * dFx(i, j - 1) - f.exf(i, j) * dFx(i, j))
-             + ih * (E(i - 1, j) - E(i, j))
-             + 0.25f * ih * (Fh(i - 1, j) - Fh(i + 1, j) + Fh(i - 1, j - 1) - Fh(i + 1, j - 1));
-    float dV = 2.f * ih * (f.eyf(i - 1, j) * dFy(i - 1, j) - f.eyf(i, j) * dFy(i, j))
-             + ih * (Fh(i, j - 1) - Fh(i, j))
-             + 0.25f * ih * (E(i, j - 1) - E(i, j + 1) + E(i - 1, j - 1) - E(i - 1, j + 1));
-    float dP = -0.5f * ih * (SX(i, j - 1) - SX(i, j + 1)) - 0.5f * ih * (SY(i - 1, j) - SY(i + 1, j));
+#pragma unroll
+  for (int r = 0; r < MA_TH / 4; ++r) {
+    const int li = (threadIdx.x >> 6) + 4 * r, lj = threadIdx.x & 63, i = i0 + li, j = j0 + lj;
+    if (i >= H || j >= W) continue;
+    const int c = (li + 1) * MA_LW + lj + 1;           // this pixel in the tile
+    auto SX = [&](int di, int dj) { return sxs[c + di * MA_LW + dj]; };
+    auto SY = [&](int di, int dj) { return sys[c + di * MA_LW + dj]; };
+    auto ET = [&](int di, int dj) { return ets[c + di * MA_LW + dj]; };
+    auto exf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di, dj + 1)); };     // x-face (i+di, j+dj+1/2)
+    auto eyf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di + 1, dj)); };     // y-face (i+di+1/2, j+dj)
+    auto dFx = [&](int di, int dj) { return ih * (SX(di, dj) - SX(di, dj + 1)); };
+    auto dTy = [&](int di, int dj) { return ih * (SX(di, dj) - SX(di + 1, dj)); };
+    auto dFy = [&](int di, int dj) { return ih * (SY(di, dj) - SY(di + 1, dj)); };
+    auto dTx = [&](int di, int dj) { return ih * (SY(di, dj) - SY(di, dj + 1)); };
+    auto E = [&](int di, int dj) { return eyf(di, dj) * dTy(di, dj); };
+    auto Fh = [&](int di, int dj) { return exf(di, dj) * dTx(di, dj); };
+    const float dU = 2.f * ih * (exf(0, -1) * dFx(0, -1) - exf(0, 0) * dFx(0, 0))
+                   + ih * (E(-1, 0) - E(0, 0))
+                   + 0.25f * ih * (Fh(-1, 0) - Fh(1, 0) + Fh(-1, -1) - Fh(1, -1));
+    const float dV = 2.f * ih * (eyf(-1, 0) * dFy(-1, 0) - eyf(0, 0) * dFy(0, 0))
+                   + ih * (Fh(0, -1) - Fh(0, 0))
+                   + 0.25f * ih * (E(0, -1) - E(0, 1) + E(-1, -1) - E(-1, 1));
+    const float dP = -0.5f * ih * (SX(0, -1) - SX(0, 1)) - 0.5f * ih * (SY(-1, 0) - SY(1, 0));
+    const size_t idx = (size_t)i * W + j;
     gu_[(size_t)n * g.pbs + idx] += s * dU;
     gv_[(size_t)n * g.pbs + idx] += s * dV;
     if (gp_) gp_[(size_t)n * g.ppbs + idx] += dP;
-    if (gT_ && t_grad) gT_[(size_t)n * g.pbs + idx] += g.ra * SY(i, j);
+    if (gT_ && t_grad) gT_[(size_t)n * g.pbs + idx] += g.ra * SY(0, 0);
   }
 }
 
@@ -511,9 +539,10 @@ int mc_momentum_adjoint(const mc_loss_desc* d, const float* T, int64_t pbs, int6
   if (rc) return rc;
   if (!T || !eta_ws || !paras || !scaler || !sx || !sy || !gu || !gv) return MC_EINVAL;
   MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
-  dim3 grid(min(cdiv(d->h * d->w, 256), 1024), d->n);
-  hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, T, eta_ws, paras, scaler, sx, sy, gu, gv, gp, gT,
-                     d->t_grad);
+  const int tiles_x = cdiv(d->w, MA_TW);
+  dim3 grid(tiles_x * cdiv(d->h, MA_TH), d->n);
+  hipLaunchKernelGGL(k_mom_adjoint, grid, dim3(256), 0, (hipStream_t)stream, g, eta_ws, scaler, sx, sy, gu, gv, gp, gT,
+                     d->t_grad, tiles_x);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
