@@ -1,6 +1,7 @@
 // Fused loss forward + backward (Trainer.loss_fn / get_loss, reference multigpu.py:122-134, 250-305)
 // and the build-defined Stokes momentum residual.  5-point stencil work on
 // [N][H][W] f32 fields: tiny next to the network, so neighbours are simply re-read through L1/L2.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -54,28 +55,17 @@ struct LossGeom {
   int64_t ppbs;     // batch stride of the p plane
 };
 
-// weight(y,x) * sign(D(y,x)) of the divergence term, 0 outside the interior
-__device__ __forceinline__ float mass_wsgn(const LossGeom& g, const float* u, const float* v, int y, int x) {
-  const int H = g.d.h, W = g.d.w;
-  if (y < 1 || y > H - 2 || x < 1 || x > W - 2 || g.d.loss_type == 0) return 0.f;
-  float D = 0.5f * (u[(size_t)y * W + x + 1] - u[(size_t)y * W + x - 1]) +
-            0.5f * (v[(size_t)(y + 1) * W + x] - v[(size_t)(y - 1) * W + x]);
-  float w;
-  if (g.d.loss_type == 1) {
-    w = 1.0f / ((float)g.d.n * (float)(H - 2) * (float)(W - 2));
-  } else {
-    float wc = 1.0f / ((float)g.d.n * (float)(H - 2)), wr = 1.0f / ((float)g.d.n * (float)(W - 2));
-    w = (x == 1 ? wc : 0.f) + (x == W - 2 ? wc : 0.f) + (y == 1 ? wr : 0.f) + (y == H - 2 ? wr : 0.f);
-  }
-  return w * sgn(D);
-}
+// tile geometry of the stencil kernels of this file: rows x 64 pixels per workgroup pass.  A/B on MI355X at
+// 32 x 506 x 506 (us, rows 8 / 16 / 32): k_loss 153 / 144 / 135, k_mom_residual 99 / 92 / 113, k_mom_adjoint 87 / 92 / 111
+constexpr int LT_TH = 32, LT_TW = 64;                    // k_loss
+constexpr int LS_LW = LT_TW + 4, LS_LH = LT_TH + 4;      // k_loss: halo 2 (divergence sign of the four neighbours)
 
 __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
                                               const float* __restrict__ p_, const float* __restrict__ T_,
                                               const float* __restrict__ uvp, const float* __restrict__ mm,
                                               double* __restrict__ sums, float* __restrict__ gu_,
                                               float* __restrict__ gv_, float* __restrict__ gp_,
-                                              float* __restrict__ gT_) {
+                                              float* __restrict__ gT_, int tiles_x, int tiles) {
   const int H = g.d.h, W = g.d.w, HW = H * W, n = blockIdx.y;
   const float* u = u_ + (size_t)n * g.pbs;
   const float* v = v_ + (size_t)n * g.pbs;
@@ -105,12 +95,46 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
   float a_us = 0, a_up = 0, a_vs = 0, a_vp = 0, a_pp = 0, a_tp = 0, a_du = 0, a_dv = 0;
   float a_m = 0, a_mx0 = 0, a_mx1 = 0, a_my0 = 0, a_my1 = 0;
 
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-    const int y = i / W, x = i % W;
+  // u, v and their targets of the tile + halo live in LDS (the per-pixel form issued ~45 global loads per pixel)
+  __shared__ float us[LS_LH * LS_LW], vs[LS_LH * LS_LW], uts[LS_LH * LS_LW], vts[LS_LH * LS_LW];
+  const float wm = 1.0f / ((float)g.d.n * (float)(H - 2) * (float)(W - 2));
+  const float wc = 1.0f / ((float)g.d.n * (float)(H - 2)), wr = 1.0f / ((float)g.d.n * (float)(W - 2));
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int y0 = (tile / tiles_x) * LT_TH, x0 = (tile % tiles_x) * LT_TW;
+    __syncthreads();                                    // the previous tile has been consumed
+    for (int t = threadIdx.x; t < LS_LH * LS_LW; t += 256) {
+      const int ly = t / LS_LW, lx = t - ly * LS_LW, yy = y0 + ly - 2, xx = x0 + lx - 2;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const size_t o = in ? (size_t)yy * W + xx : 0;
+      us[t] = in ? u[o] : 0.f;
+      vs[t] = in ? v[o] : 0.f;
+      uts[t] = in ? ut[o] : 0.f;
+      vts[t] = in ? vt[o] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+  for (int r = 0; r < LT_TH / 4; ++r) {
+    const int ly = (threadIdx.x >> 6) + 4 * r, lx = threadIdx.x & 63, y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) continue;
+    const int i = y * W + x;
+    const int cc = (ly + 2) * LS_LW + lx + 2;
+    auto U = [&](int dy, int dx) { return us[cc + dy * LS_LW + dx]; };
+    auto V = [&](int dy, int dx) { return vs[cc + dy * LS_LW + dx]; };
+    auto UT = [&](int dy, int dx) { return uts[cc + dy * LS_LW + dx]; };
+    auto VT = [&](int dy, int dx) { return vts[cc + dy * LS_LW + dx]; };
+    // weight * sign(D) of the divergence term at (y + dy, x + dx), 0 outside the interior
+    auto mass_wsgn = [&](int dy, int dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 1 || yy > H - 2 || xx < 1 || xx > W - 2) return 0.f;
+      const float D = 0.5f * (U(dy, dx + 1) - U(dy, dx - 1)) + 0.5f * (V(dy + 1, dx) - V(dy - 1, dx));
+      const float w = g.d.loss_type == 1 ? wm
+                    : (xx == 1 ? wc : 0.f) + (xx == W - 2 ? wc : 0.f) + (yy == 1 ? wr : 0.f) + (yy == H - 2 ? wr : 0.f);
+      return w * sgn(D);
+    };
     const float bw = (g.d.loss_scale && (y < 2 || y >= H - 2 || x < 2 || x >= W - 2)) ? 11.f : 1.f;
     float gu = 0.f, gv = 0.f, gp = 0.f, gT = 0.f;
     {  // data terms
-      float du = ut[i] - u[i], dv = vt[i] - v[i], dT = hasT ? Tt[i] - T[i] : 0.f;
+      float du = UT(0, 0) - U(0, 0), dv = VT(0, 0) - V(0, 0), dT = hasT ? Tt[i] - T[i] : 0.f;
       float wu = su * bw, wv = sv * bw;
       if (!g.d.l2) {
         a_us += fabsf(du * wu); a_up += fabsf(du);
@@ -133,26 +157,26 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
     if (g.d.loss_derivative) {
       // e_u[y'] = 126 ((ut[y'+1]-ut[y']) - (u[y'+1]-u[y'])), y' in [0,H-3]  (dy_top, multigpu.py:277-284)
       if (y <= H - 3) {
-        float e = (ut[i + W] - ut[i]) - (u[i + W] - u[i]);
+        float e = (UT(1, 0) - UT(0, 0)) - (U(1, 0) - U(0, 0));
         a_du += fabsf(126.0f * e);
         gu += cdu * sgn(e);
       }
       if (y >= 1 && y <= H - 2) {
-        float e = (ut[i] - ut[i - W]) - (u[i] - u[i - W]);
+        float e = (UT(0, 0) - UT(-1, 0)) - (U(0, 0) - U(-1, 0));
         gu -= cdu * sgn(e);
       }
       if (x <= W - 3) {
-        float e = (vt[i + 1] - vt[i]) - (v[i + 1] - v[i]);
+        float e = (VT(0, 1) - VT(0, 0)) - (V(0, 1) - V(0, 0));
         a_dv += fabsf(126.0f * e);
         gv += cdv * sgn(e);
       }
       if (x >= 1 && x <= W - 2) {
-        float e = (vt[i] - vt[i - 1]) - (v[i] - v[i - 1]);
+        float e = (VT(0, 0) - VT(0, -1)) - (V(0, 0) - V(0, -1));
         gv -= cdv * sgn(e);
       }
     }
     if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
-      float D = 0.5f * (u[i + 1] - u[i - 1]) + 0.5f * (v[i + W] - v[i - W]);
+      float D = 0.5f * (U(0, 1) - U(0, -1)) + 0.5f * (V(1, 0) - V(-1, 0));
       float m = fabsf(D);
       a_m += m;
       if (x == 1) a_mx0 += m;
@@ -161,13 +185,14 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
       if (y == H - 2) a_my1 += m;
     }
     if (g.d.loss_type != 0) {
-      gu += 0.5f * (mass_wsgn(g, u, v, y, x - 1) - mass_wsgn(g, u, v, y, x + 1));
-      gv += 0.5f * (mass_wsgn(g, u, v, y - 1, x) - mass_wsgn(g, u, v, y + 1, x));
+      gu += 0.5f * (mass_wsgn(0, -1) - mass_wsgn(0, 1));
+      gv += 0.5f * (mass_wsgn(-1, 0) - mass_wsgn(1, 0));
     }
     gu_[(size_t)n * g.pbs + i] = gu;
     gv_[(size_t)n * g.pbs + i] = gv;
     if (gp_) gp_[(size_t)n * g.ppbs + i] = gp;
     if (gT_) gT_[(size_t)n * g.pbs + i] = g.d.t_grad ? gT : 0.f;
+  }
   }
   BlockSums bs;
   bs.v[0] = a_us; bs.v[1] = a_up; bs.v[2] = a_vs; bs.v[3] = a_vp; bs.v[4] = a_pp; bs.v[5] = a_tp; bs.v[6] = a_du;
@@ -186,72 +211,79 @@ struct MomGeom {
   float ih, ra, lam;
 };
 
-struct MomField {
-  const float* etab; int H, W;     // viscosity field of this sample, precomputed once by k_mom_eta
-  __device__ __forceinline__ float eta(int i, int j) const { return etab[(size_t)i * W + j]; }
-  __device__ __forceinline__ float exf(int i, int j) const {  // x-face (i, j+1/2)
-    if (i < 0 || i >= H || j < 0 || j > W - 2) return 0.f;
-    return 0.5f * (eta(i, j) + eta(i, j + 1));
-  }
-  __device__ __forceinline__ float eyf(int i, int j) const {  // y-face (i+1/2, j)
-    if (i < 0 || i > H - 2 || j < 0 || j >= W) return 0.f;
-    return 0.5f * (eta(i, j) + eta(i + 1, j));
-  }
-  // the same faces where the caller knows they lie inside the domain
-  __device__ __forceinline__ float exf_in(int i, int j) const { return 0.5f * (eta(i, j) + eta(i, j + 1)); }
-  __device__ __forceinline__ float eyf_in(int i, int j) const { return 0.5f * (eta(i, j) + eta(i + 1, j)); }
-};
-
-// eta = clip(exp(-ln(FKT) T + ln(FKP) (1 - y)), 1e-8, 1): one exp per pixel instead of ~20 per residual evaluation
-__global__ void k_mom_eta(int HW, int64_t pbs, const float* __restrict__ T_, const float* __restrict__ yc,
-                          const float* __restrict__ paras, float* __restrict__ eta) {
-  const int n = blockIdx.y;
-  const float lnfkt = logf(paras[n * 3 + 1]), lnfkp = logf(paras[n * 3 + 2]);
-  const float* T = T_ + (size_t)n * pbs;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-    float e = expf(-lnfkt * T[i] + lnfkp * (1.0f - yc[i]));
-    eta[(size_t)n * HW + i] = fminf(fmaxf(e, 1e-8f), 1.0f);
-  }
-}
-
+// Residual, LDS-tiled like the adjoint below: a block walks 8 x 64 pixel tiles of its sample; s*u, s*v, p and the
+// viscosity eta = clip(exp(-ln(FKT) T + ln(FKP) (1 - y)), 1e-8, 1) of the tile + a one-pixel halo are staged once (eta is
+// evaluated here, 1.3 exp per pixel, and its centre values are kept in eta_out for the adjoint), then every face is formed
+// from LDS.  The per-pixel form issued ~35 global loads per pixel.
+constexpr int MA_TW = LT_TW, MA_LW = MA_TW + 2;         // momentum kernels: halo 1
+constexpr int MR_TH = 16, MR_LH = MR_TH + 2;            // residual
+constexpr int MA_TH = 8, MA_LH = MA_TH + 2;             // adjoint
 __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __restrict__ u_, const float* __restrict__ v_,
                                                       const float* __restrict__ p_, const float* __restrict__ T_,
-                                                      const float* __restrict__ eta_, const float* __restrict__ paras,
+                                                      const float* __restrict__ yc, const float* __restrict__ paras,
                                                       const float* __restrict__ scaler, double* __restrict__ sums,
-                                                      float* __restrict__ sx_, float* __restrict__ sy_) {
+                                                      float* __restrict__ sx_, float* __restrict__ sy_,
+                                                      float* __restrict__ eta_out, int tiles_x, int tiles) {
   const int H = g.H, W = g.W, HW = H * W, n = blockIdx.y;
   const float* u = u_ + (size_t)n * g.pbs;
   const float* v = v_ + (size_t)n * g.pbs;
   const float* p = p_ ? p_ + (size_t)n * g.ppbs : nullptr;
   const float* T = T_ + (size_t)n * g.pbs;
-  MomField f{eta_ + (size_t)n * HW, H, W};
+  const float lnfkt = logf(paras[n * 3 + 1]), lnfkp = logf(paras[n * 3 + 2]);
   const float s = scaler[n], ih = g.ih;
   const float c = g.lam / ((float)g.N * (float)(H - 2) * (float)(W - 2));
+  __shared__ float us[MR_LH * MA_LW], vs[MR_LH * MA_LW], ps[MR_LH * MA_LW], es[MR_LH * MA_LW];
   float ax = 0, ay = 0;      // per-thread f32 partials (see k_loss)
-  auto U = [&](int i, int j) { return s * u[(size_t)i * W + j]; };
-  auto V = [&](int i, int j) { return s * v[(size_t)i * W + j]; };
-  auto P = [&](int i, int j) { return p ? p[(size_t)i * W + j] : 0.f; };
-  auto dVdx = [&](int i, int j) { return 0.5f * (V(i, j + 1) - V(i, j - 1)) * ih; };
-  auto dUdy = [&](int i, int j) { return 0.5f * (U(i + 1, j) - U(i - 1, j)) * ih; };
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW; idx += gridDim.x * blockDim.x) {
-    const int i = idx / W, j = idx % W;
-    float ox = 0.f, oy = 0.f;
-    if (i >= 1 && i <= H - 2 && j >= 1 && j <= W - 2) {
-      float Fx1 = 2.f * f.exf_in(i, j) * (U(i, j + 1) - U(i, j)) * ih;
-      float Fx0 = 2.f * f.exf_in(i, j - 1) * (U(i, j) - U(i, j - 1)) * ih;
-      float Ty1 = f.eyf_in(i, j) * ((U(i + 1, j) - U(i, j)) * ih + 0.5f * (dVdx(i, j) + dVdx(i + 1, j)));
-      float Ty0 = f.eyf_in(i - 1, j) * ((U(i, j) - U(i - 1, j)) * ih + 0.5f * (dVdx(i - 1, j) + dVdx(i, j)));
-      float Rx = -0.5f * (P(i, j + 1) - P(i, j - 1)) * ih + (Fx1 - Fx0) * ih + (Ty1 - Ty0) * ih;
-      float Fy1 = 2.f * f.eyf_in(i, j) * (V(i + 1, j) - V(i, j)) * ih;
-      float Fy0 = 2.f * f.eyf_in(i - 1, j) * (V(i, j) - V(i - 1, j)) * ih;
-      float Tx1 = f.exf_in(i, j) * ((V(i, j + 1) - V(i, j)) * ih + 0.5f * (dUdy(i, j) + dUdy(i, j + 1)));
-      float Tx0 = f.exf_in(i, j - 1) * ((V(i, j) - V(i, j - 1)) * ih + 0.5f * (dUdy(i, j - 1) + dUdy(i, j)));
-      float Ry = -0.5f * (P(i + 1, j) - P(i - 1, j)) * ih + (Fy1 - Fy0) * ih + (Tx1 - Tx0) * ih + g.ra * T[idx];
-      ax += fabsf(Rx); ay += fabsf(Ry);
-      ox = c * sgn(Rx); oy = c * sgn(Ry);
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int i0 = (tile / tiles_x) * MR_TH, j0 = (tile % tiles_x) * MA_TW;
+    __syncthreads();                                    // the previous tile has been consumed
+    for (int t = threadIdx.x; t < MR_LH * MA_LW; t += 256) {
+      const int li = t / MA_LW, lj = t - li * MA_LW, i = i0 + li - 1, j = j0 + lj - 1;
+      const bool in = i >= 0 && i < H && j >= 0 && j < W;
+      const size_t o = in ? (size_t)i * W + j : 0;
+      float e = 0.f;
+      if (in) {
+        e = fminf(fmaxf(expf(-lnfkt * T[o] + lnfkp * (1.0f - yc[o])), 1e-8f), 1.0f);
+        if (li >= 1 && li <= MR_TH && lj >= 1 && lj <= MA_TW) eta_out[(size_t)n * HW + o] = e;
+      }
+      us[t] = in ? s * u[o] : 0.f;
+      vs[t] = in ? s * v[o] : 0.f;
+      ps[t] = (in && p) ? p[o] : 0.f;
+      es[t] = e;
     }
-    sx_[(size_t)n * HW + idx] = ox;
-    sy_[(size_t)n * HW + idx] = oy;
+    __syncthreads();
+#pragma unroll 2
+    for (int r = 0; r < MR_TH / 4; ++r) {
+      const int li = (threadIdx.x >> 6) + 4 * r, lj = threadIdx.x & 63, i = i0 + li, j = j0 + lj;
+      if (i >= H || j >= W) continue;
+      const size_t idx = (size_t)i * W + j;
+      float ox = 0.f, oy = 0.f;
+      if (i >= 1 && i <= H - 2 && j >= 1 && j <= W - 2) {     // every face below lies inside the domain
+        const int cc = (li + 1) * MA_LW + lj + 1;
+        auto U = [&](int di, int dj) { return us[cc + di * MA_LW + dj]; };
+        auto V = [&](int di, int dj) { return vs[cc + di * MA_LW + dj]; };
+        auto P = [&](int di, int dj) { return ps[cc + di * MA_LW + dj]; };
+        auto ET = [&](int di, int dj) { return es[cc + di * MA_LW + dj]; };
+        auto exf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di, dj + 1)); };   // x-face (i+di, j+dj+1/2)
+        auto eyf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di + 1, dj)); };   // y-face (i+di+1/2, j+dj)
+        auto dVdx = [&](int di, int dj) { return 0.5f * (V(di, dj + 1) - V(di, dj - 1)) * ih; };
+        auto dUdy = [&](int di, int dj) { return 0.5f * (U(di + 1, dj) - U(di - 1, dj)) * ih; };
+        float Fx1 = 2.f * exf(0, 0) * (U(0, 1) - U(0, 0)) * ih;
+        float Fx0 = 2.f * exf(0, -1) * (U(0, 0) - U(0, -1)) * ih;
+        float Ty1 = eyf(0, 0) * ((U(1, 0) - U(0, 0)) * ih + 0.5f * (dVdx(0, 0) + dVdx(1, 0)));
+        float Ty0 = eyf(-1, 0) * ((U(0, 0) - U(-1, 0)) * ih + 0.5f * (dVdx(-1, 0) + dVdx(0, 0)));
+        float Rx = -0.5f * (P(0, 1) - P(0, -1)) * ih + (Fx1 - Fx0) * ih + (Ty1 - Ty0) * ih;
+        float Fy1 = 2.f * eyf(0, 0) * (V(1, 0) - V(0, 0)) * ih;
+        float Fy0 = 2.f * eyf(-1, 0) * (V(0, 0) - V(-1, 0)) * ih;
+        float Tx1 = exf(0, 0) * ((V(0, 1) - V(0, 0)) * ih + 0.5f * (dUdy(0, 0) + dUdy(0, 1)));
+        float Tx0 = exf(0, -1) * ((V(0, 0) - V(0, -1)) * ih + 0.5f * (dUdy(0, -1) + dUdy(0, 0)));
+        float Ry = -0.5f * (P(1, 0) - P(-1, 0)) * ih + (Fy1 - Fy0) * ih + (Tx1 - Tx0) * ih + g.ra * T[idx];
+        ax += fabsf(Rx); ay += fabsf(Ry);
+        ox = c * sgn(Rx); oy = c * sgn(Ry);
+      }
+      sx_[(size_t)n * HW + idx] = ox;
+      sy_[(size_t)n * HW + idx] = oy;
+    }
   }
   BlockSums bs;
   bs.v[0] = ax; bs.v[1] = ay;
@@ -264,7 +296,6 @@ __global__ __launch_bounds__(256) void k_mom_residual(MomGeom g, const float* __
 // S is zero on the outermost ring and beyond (k_mom_residual writes 0 there), so every difference of S that an
 // out-of-domain face would multiply is itself zero, and the zero-filled eta keeps those faces finite.
 // (The straight per-pixel form issued ~40 bounds-checked global loads per pixel: 235 us at 32 x 506 x 506.)
-constexpr int MA_TH = 8, MA_TW = 64, MA_LW = MA_TW + 2, MA_LH = MA_TH + 2;
 __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __restrict__ eta_,
                                                      const float* __restrict__ scaler,
                                                      const float* __restrict__ sx_, const float* __restrict__ sy_,
@@ -286,7 +317,7 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
   }
   __syncthreads();
   const float s = scaler[n], ih = g.ih;
-#pragma unroll
+#pragma unroll 2
   for (int r = 0; r < MA_TH / 4; ++r) {
     const int li = (threadIdx.x >> 6) + 4 * r, lj = threadIdx.x & 63, i = i0 + li, j = j0 + lj;
     if (i >= H || j >= W) continue;
@@ -477,7 +508,8 @@ __global__ void k_loss_finalize(mc_loss_desc d, const double* __restrict__ s, fl
 // workgroups per sample for the reducing loss kernels: every block ends in one f64 atomic per slot on a handful of
 // addresses (serialised at ~10 ns each), so keep the total near 2-4 blocks per CU and grid-stride the pixels
 int loss_blocks(int hw, int n) {
-  int b = cdiv(1024, n);
+  static const int total = [] { const char* e = getenv("MC_LOSS_BLOCKS"); return e ? atoi(e) : 1024; }();   // A/B knob
+  int b = cdiv(total, n);
   int most = cdiv(hw, 256);
   if (b > most) b = most;
   return b < 1 ? 1 : b;
@@ -511,9 +543,10 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
   if (d->loss_scale && !mm) return MC_EINVAL;
   LossGeom g;
   g.d = *d; g.ct = (d->p_pred ? 3 : 2) + (hasT ? 1 : 0); g.pbs = pbs; g.ppbs = ppbs;
-  dim3 grid(loss_blocks(d->h * d->w, d->n), d->n);
+  const int tiles_x = cdiv(d->w, LT_TW), tiles = tiles_x * cdiv(d->h, LT_TH);
+  dim3 grid(min(loss_blocks(d->h * d->w, d->n), tiles), d->n);
   hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
-                     gu, gv, d->p_pred ? gp : nullptr, hasT ? gT : nullptr);
+                     gu, gv, d->p_pred ? gp : nullptr, hasT ? gT : nullptr, tiles_x, tiles);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -525,9 +558,10 @@ int mc_momentum_residual(const mc_loss_desc* d, const float* u, const float* v, 
   if (rc) return rc;
   if (!u || !v || !T || !yc || !paras || !scaler || !sums || !sx || !sy || !eta_ws || d->t_grad < 0) return MC_EINVAL;
   MomGeom g{d->n, d->h, d->w, pbs, ppbs, d->inv_h, d->ra, d->lambda_mom};
-  dim3 grid(loss_blocks(d->h * d->w, d->n), d->n);
-  hipLaunchKernelGGL(k_mom_eta, grid, dim3(256), 0, (hipStream_t)stream, d->h * d->w, pbs, T, yc, paras, eta_ws);
-  hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, eta_ws, paras, scaler, sums, sx, sy);
+  const int tiles_x = cdiv(d->w, MA_TW), tiles = tiles_x * cdiv(d->h, MR_TH);
+  dim3 grid(min(2 * loss_blocks(d->h * d->w, d->n), tiles), d->n);      // two sums only: 2048 blocks measured best
+  hipLaunchKernelGGL(k_mom_residual, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, p, T, yc, paras, scaler, sums, sx, sy, eta_ws,
+                     tiles_x, tiles);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
