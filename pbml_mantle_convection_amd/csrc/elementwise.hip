@@ -8,17 +8,32 @@ namespace {
 // =================================================================================================
 // NCHW f32 <-> CB8
 // =================================================================================================
+// flat index -> (x, y, channel block, sample); 32-bit divisions when the tensor allows it (the three 64-bit div/mod
+// pairs were most of the instructions of the boundary-conversion kernels)
+__device__ __forceinline__ void split_index(size_t i, bool small, int Wd, int H, int C8, int& xo, int& y, int& cb, int& n) {
+  if (small) {
+    unsigned r = (unsigned)i;
+    xo = (int)(r % (unsigned)Wd); r /= (unsigned)Wd;
+    y = (int)(r % (unsigned)H); r /= (unsigned)H;
+    cb = (int)(r % (unsigned)C8);
+    n = (int)(r / (unsigned)C8);
+  } else {
+    xo = (int)(i % Wd);
+    size_t r = i / Wd;
+    y = (int)(r % H); r /= H;
+    cb = (int)(r % C8);
+    n = (int)(r / C8);
+  }
+}
+
 template <typename T>
 __global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int SC, int H, int W, int pad_w, int mode,
                             const float* __restrict__ cs, T* __restrict__ out) {
   const int Wp = W + 2 * pad_w, C8 = (C + 7) / 8;
   size_t total = (size_t)N * C8 * H * Wp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int xo = (int)(i % Wp);
-    size_t r = i / Wp;
-    int y = (int)(r % H); r /= H;
-    int cb = (int)(r % C8);
-    int n = (int)(r / C8);
+    int xo, y, cb, n;
+    split_index(i, total <= 0xffffffffull, Wp, H, C8, xo, y, cb, n);
     int xs = pad_map(xo - pad_w, W, mode);
     float v[8];
 #pragma unroll
@@ -36,11 +51,8 @@ __global__ void k_unpack_nchw(const T* __restrict__ x, int N, int C, int H, int 
   const int Wo = W - 2 * crop, C8 = (C + 7) / 8;
   size_t total = (size_t)N * C8 * H * Wo;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int xo = (int)(i % Wo);
-    size_t r = i / Wo;
-    int y = (int)(r % H); r /= H;
-    int cb = (int)(r % C8);
-    int n = (int)(r / C8);
+    int xo, y, cb, n;
+    split_index(i, total <= 0xffffffffull, Wo, H, C8, xo, y, cb, n);
     float v[8];
     V8<T>::ld(x + cb8_index(n, cb, y, xo + crop, C8, H, W), v);
 #pragma unroll
@@ -60,11 +72,8 @@ __global__ void k_pack_grad_nchw(const float* __restrict__ g, int N, int C, int 
   const int Wi = W - 2 * crop, C8 = (C + 7) / 8;
   size_t total = (size_t)N * C8 * H * W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int xo = (int)(i % W);
-    size_t r = i / W;
-    int y = (int)(r % H); r /= H;
-    int cb = (int)(r % C8);
-    int n = (int)(r / C8);
+    int xo, y, cb, n;
+    split_index(i, total <= 0xffffffffull, W, H, C8, xo, y, cb, n);
     int xi = xo - crop;
     float v[8];
 #pragma unroll
@@ -90,7 +99,17 @@ __global__ void k_sum_hw(const float* __restrict__ x, int hw, float scale, float
   // grid (chunks, nc): each block reduces a slice of one plane and adds it to out[nc] (zeroed by the caller)
   const float* p = x + (size_t)blockIdx.y * hw;
   float s = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) s += p[i];
+  if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {        // planes are 16-byte aligned: 4 pixels per load
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw / 4; i += gridDim.x * blockDim.x) {
+      const float4 v = p4[i];
+      s += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    s = (s + s1) + (s2 + s3);
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) s += p[i];
+  }
   s = wave_sum(s);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
