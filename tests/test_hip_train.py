@@ -40,8 +40,16 @@ def _case(B, H, W, seed, p_pred):
 @pytest.mark.parametrize("loss_type", ["mae", "mass"])
 @pytest.mark.parametrize("ls,ld,norm", [(False, False, "l1"), (True, True, "l1"), (True, False, "l2")])
 def test_fused_loss_matches_oracle(p_pred, loss_type, ls, ld, norm):
+    _fused_loss_case(p_pred, loss_type, ls, ld, norm, 2, 37, 53)
+
+
+@pytest.mark.parametrize("H,W", [(70, 131), (5, 200), (33, 65)])       # several ragged LDS tiles in x and y; minimum height
+def test_fused_loss_matches_oracle_multi_tile(H, W):
+    _fused_loss_case(True, "mass", True, True, "l1", 2, H, W)
+
+
+def _fused_loss_case(p_pred, loss_type, ls, ld, norm, B, H, W):
     from pbml_mantle_convection_amd.losses import StokesLoss
-    B, H, W = 2, 37, 53
     u, v, p, T, uvp = _case(B, H, W, 100, p_pred)
     chans = [u, v, T] + ([p] if p_pred else [])
     y = dev(np.stack(chans, 1))
@@ -78,9 +86,10 @@ def test_fused_loss_curl_matches_oracle(p_pred):
     close(gy, ty.grad, atol=1e-8, rtol=2e-4, what="gy")
 
 
-def test_momentum_residual_matches_oracle():
+@pytest.mark.parametrize("H,W", [(29, 41), (70, 131), (5, 200)])       # one tile; 3 x 9 ragged tiles; the minimum height
+def test_momentum_residual_matches_oracle(H, W):
     from pbml_mantle_convection_amd.losses import StokesLoss
-    B, H, W = 2, 29, 41
+    B = 2
     u, v, p, T, uvp = _case(B, H, W, 300, True)
     paras = fields.sim_parameters(B, 5)
     paras[:, 1] = 10.0 ** np.array([2.0, 3.0])      # moderate viscosity contrast keeps the f32 sign pattern stable
