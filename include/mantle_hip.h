@@ -152,6 +152,13 @@ int mc_gn_partials(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, in
  * per-(n,c) means of y when chan_mean != NULL (Unet's spatial zero-mean, :2024). */
 int mc_gn_finalize(const float* stat_partials, int32_t n, int32_t tiles, int32_t c, int32_t groups,
                    int32_t hw, float eps, float* stats_ng2, float* chan_mean, void* stream);
+/* Traversal direction of the launches that follow (process-wide, read at launch time, so a HIP-graph capture records it per
+ * kernel): reverse != 0 makes the batch-streaming kernels (mc_conv2d, mc_conv2d_wgrad in bf16 mode, mc_gn_act_fwd,
+ * mc_gn_act_bwd_reduce / _apply) walk their samples / work items from the last to the first.  Results are identical; a
+ * consumer that runs opposite to its producer starts on the bytes written last, which are still in the 256 MiB Infinity
+ * Cache.  No counterpart in the reference (scheduling only). */
+int mc_set_direction(int32_t reverse);
+
 /* a = act(GN(y));  post = MC_POST_*.  pool > 1 additionally writes AvgPool2d(pool)(a) into
  * pooled (Unet :2002, ConvAE :1051).  y, a, pooled are CB8 of `dtype`. */
 int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mc_unpack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
+    "mc_set_direction": (C.c_int, [_i32]),
     "mc_packed_weight_bytes": (_sz, [_CD, _i32]),
     "mc_pack_weights": (C.c_int, [_CD, _vp, _i32, _vp, _vp]),
     "mc_conv_tiles": (_i32, [_CD]),

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   }
   auto prefetch = [&](int t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
-    const int wi = bid + jitem * gridDim.x;
+    const int wi = g.rev ? items - 1 - (bid + jitem * (int)gridDim.x) : bid + jitem * (int)gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
     if (ck != chunks - 1) continue;
 
     // ---- epilogue of this work item, straight from the accumulators
-    const int wi = bid + jitem * gridDim.x;
+    const int wi = g.rev ? items - 1 - (bid + jitem * (int)gridDim.x) : bid + jitem * (int)gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     f32x2 s1[NT][2], s2[NT][2];                                  // per-lane (sum, sum of squares) of channel pairs
@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
   }
 
   uint4 rx[X_ITERS], rd[D_ITERS];
-  auto prefetch = [&](int wi) __attribute__((always_inline)) {
+  auto prefetch = [&](int wi_fwd) __attribute__((always_inline)) {
+    const int wi = g.rev ? g.N * tiles - 1 - wi_fwd : wi_fwd;
     const int n = wi / tiles, tile = wi - n * tiles;
     const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
@@ -835,8 +836,10 @@ const char* mc_bf16_kernel_name(const ConvGeom& g) {
   return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4,false>" : "k_conv_mfma_bf16<3,16,16,4,4,false>");
 }
 
-int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
+int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
                    void* y1, float* part, hipStream_t s) {
+  ConvGeom g = g_in;
+  g.rev = mc_g_reverse;
   Bf16Cfg c = cfg_for(g.Cout);
   int nt_total = (g.Cout + 15) / 16;
   int groups = (nt_total + c.nt - 1) / c.nt;
@@ -863,7 +866,9 @@ int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void
   return MC_OK;
 }
 
-int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s) {
+int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s) {
+  ConvGeom g = g_in;
+  g.rev = mc_g_reverse;
   const int tiles_x = (g.Wo + WTW - 1) / WTW, tiles_y = (g.Ho + WTH - 1) / WTH;
   const int tiles = tiles_x * tiles_y;
   const int ntiles = (g.Cout + 15) / 16;

@@ -215,7 +215,7 @@ static int gn_fwd_vpt() { static int v = env_int("MC_GN_FWD_VPT", 8); return v; 
 static int gn_apply_rows(int h, int w) { static int v = env_int("MC_GN_ROWS", 0); if (v > 0) return v; return w > 256 ? GN_ROWS : (w > 32 ? 16 : 32); }
 
 struct GnArgs {
-  int N, C, C8, H, W, groups, cpg, post, act;
+  int N, C, C8, H, W, groups, cpg, post, act, rev;
   const float* stats;
   const float* gamma;
   const float* beta;
@@ -243,7 +243,7 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
   // one thread per POOLxPOOL pixel block of one channel block
   const int Hb = (a.H + POOL - 1) / POOL, Wb = (a.W + POOL - 1) / POOL;
   const int Hp = a.H / POOL, Wp = a.W / POOL;
-  const int n = blockIdx.z, cb = blockIdx.y;
+  const int n = a.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8];
   gn_coef(a, n, cb, sc, sh);
   const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
@@ -314,7 +314,7 @@ static int gkind_of(const mc_grad_src& g0, const mc_grad_src& g1) {
 template <typename T, int GK>
 __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
                                                        mc_grad_src g1, float* __restrict__ part, int CP) {
-  const int n = blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int n = a.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   float sc[8], sh[8], mean[8], rstd[8];
   gn_coef(a, n, cb, sc, sh);
 #pragma unroll
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
                                                       mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy,
                                                       const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta, int rows_pb) {
-  const int n = blockIdx.z, cb = blockIdx.y;
+  const int n = a.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8], mean[8], rstd[8], ga[8], m1[8], m2[8];
   gn_coef(a, n, cb, sc, sh);
   __shared__ float fsum[4][16];
@@ -1005,7 +1005,12 @@ inline dim3 grid3(int per_plane, int c8, int n, int block = 256, int capx = 64) 
 // ====================================================================================================
 // C ABI
 // ====================================================================================================
+int mc_g_reverse = 0;
+
 extern "C" {
+
+int mc_set_direction(int32_t reverse) { mc_g_reverse = reverse ? 1 : 0; return MC_OK; }
+
 
 int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
                  int32_t pad_mode, const float* chan_scale, int32_t dtype, void* out, void* stream) {
@@ -1094,6 +1099,7 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
                   const float* gamma, const float* beta, int32_t post, int32_t act, int32_t pool, int32_t dtype,
                   void* a_out, void* pooled, void* stream) {
   GnArgs a;
+  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (!y || !a_out || (pool > 1 && !pooled)) return MC_EINVAL;
@@ -1154,6 +1160,7 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
                          const float* gamma, const float* beta, int32_t post, int32_t act, int32_t dtype,
                          const mc_grad_src* g0, const mc_grad_src* g1, float* partials, void* stream) {
   GnArgs a;
+  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (post != MC_POST_GN_ACT || !y || !partials || !g0) return MC_EINVAL;
@@ -1184,6 +1191,7 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
                         const float* m12, const float* gamma, const float* beta, int32_t post, int32_t act,
                         int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream) {
   GnArgs a;
+  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (!y || !dy || !g0 || (post == MC_POST_GN_ACT && !m12)) return MC_EINVAL;
@@ -1224,6 +1232,7 @@ int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, in
                               int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, float* dgamma, float* dbeta,
                               void* dy, void* stream) {
   GnArgs a;
+  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, MC_POST_GN_ACT, act);
   if (rc) return rc;
   if (!y || !dy || !g0 || !partials || blocks <= 0) return MC_EINVAL;

@@ -359,6 +359,11 @@ class Engine:
         # filter-gradient kernels on a second stream: 0 = never, 1 = every layer, 2 = only layers of <= 128 x 128 pixels
         # (their launches are latency-bound and leave most of the chip idle)
         self.wfin_per_layer = os.environ.get("MANTLE_WFIN_PER_LAYER", "1") != "0"   # A/B on MI355X: -0.14 ms/step (the combine leaves the tail of the step)
+        # traversal direction of the batch-streaming kernels (mc_set_direction): 0 = every kernel walks the batch first to
+        # last; 1 = every kernel of the dependent chain runs opposite to its predecessor, so it starts on the bytes written
+        # last (Infinity Cache); 2 = only the GroupNorm kernels run reversed
+        self.zigzag = int(os.environ.get("MANTLE_ZIGZAG", "0"))
+        self._dirn = 0
         self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "1"))   # A/B on MI355X: 1 is 0.25 ms/step faster than 0, 2 is no gain
 
     # -------------------------------------------------------------- planning
@@ -593,6 +598,20 @@ class Engine:
         return self._tables[key]
 
     # -------------------------------------------------------------- forward
+    def _direction(self, kind: str):
+        """Set the traversal direction for the next launch of the dependent chain (kind: 'conv' | 'gn_rev' | 'gn_fwd' | 'keep' |
+        'reset')."""
+        if not self.zigzag:
+            return
+        if kind == "reset":
+            self._dirn = 0
+        elif self.zigzag == 1:
+            if kind != "keep":
+                self._dirn ^= 1
+        else:
+            self._dirn = 1 if kind == "gn_rev" else 0
+        L.call("mc_set_direction", self._dirn)
+
     def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], chan_scale=None) -> torch.Tensor:
         """x: [N, >= c_in, H, W] f32 device tensor (extra trailing channels are ignored)
         -> [N, c_out, H', W'] f32.  chan_scale: optional [c_in] f32 per-channel input scale."""
@@ -649,6 +668,7 @@ class Engine:
             if node.learned:
                 self._learned_forward(e, srcs[0], params, need_part, st)
             else:
+                self._direction("conv")
                 self._probe_begin()
                 L.call("mc_conv2d", C.byref(d), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf) if len(srcs) > 1 else None,
                        L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None, L.ptr(e["part"]) if need_part else None, st)
@@ -660,6 +680,7 @@ class Engine:
                 gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
                 beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
                 pooled = T[node.pooled].buf if node.pool > 1 else None
+                self._direction("gn_rev")
                 L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                        L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype,
                        L.ptr(o.buf), L.ptr(pooled), st)
@@ -669,6 +690,7 @@ class Engine:
         fo = T[self.plan[-1]["node"].out]
         out = torch.empty((N, g.c_out, self.out_h, self.out_w), dtype=torch.float32, device=x.device)
         out_dt = L.MC_F32 if fo.buf.dtype == torch.float32 else self.mc_dtype
+        self._direction("reset")
         L.call("mc_unpack_nchw", L.ptr(fo.buf), N, fo.C, fo.H, fo.W, g.crop_w, L.ptr(self.chan_mean), out_dt,
                L.ptr(out), st)
         return out
@@ -770,6 +792,7 @@ class Engine:
                 beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
                 cpg = node.c_out // max(node.groups, 1)
                 if node.post == L.POST_GN_ACT:
+                    self._direction("gn_rev")
                     L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
                            L.ptr(e["gpart"]), st)
@@ -784,6 +807,7 @@ class Engine:
                         L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
                                o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
                                L.ptr(grads[node.gn_name + "bias"]), st)
+                    self._direction("gn_fwd")
                     L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
                            self.mc_dtype, g0, g1, L.ptr(dY), st)
@@ -799,6 +823,7 @@ class Engine:
                 ev = torch.cuda.Event()
                 ev.record(main)                           # dY of this layer is complete
                 side.wait_event(ev)
+            self._direction("conv")                    # the filter and the input gradient both start on the dY written last
             with torch.cuda.stream(side):
                 ss = L.stream()
                 L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(e["wpart"]), ss)
@@ -815,6 +840,7 @@ class Engine:
             k += 1
             if e["need_dgrad"]:
                 dxp = e["dxp"]
+                self._direction("keep")
                 self._probe_begin()
                 L.call("mc_conv2d", C.byref(e["ddesc"]), L.ptr(dY), None, L.ptr(e["dbank"]), None, L.ptr(dxp[0]),
                        L.ptr(dxp[1]) if len(dxp) > 1 else None, None, st)
@@ -825,6 +851,7 @@ class Engine:
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(self.side)
+        self._direction("reset")
         # one launch combines every layer's partial slabs, folds mirrored filters and accumulates into the gradients
         todo = [e for e in self.convs if not e.get("_wfin_done")]
         n = len(todo)
