@@ -79,6 +79,33 @@ typedef struct {
   int32_t cb_off;     /* the slice starting at block cb_off (gradient of one torch.cat operand)   */
 } mc_grad_src;
 
+/* "Normalise on load": a consumer of a raw conv output y applies act(scale * y + shift) — GroupNorm's affine map folded
+ * with its statistics, then the activation (FluidLayer.forward, pytorch_networks_convae.py:790-799) — while it stages its
+ * input tile, so the activated tensor never crosses HBM.  coef tables: [n][ceil(c/8)*8][4] f32 = (scale, shift, mean,
+ * rstd) per (sample, channel) from mc_gn_finalize_coef; NULL = no affine map.  act = MC_ACT_NONE with a NULL table
+ * means the source is used as it is (network input, pooled / upsampled tensors). */
+typedef struct {
+  const float* coef0; /* source 0 */
+  const float* coef1; /* source 1 (second torch.cat operand) */
+  int32_t act0, act1; /* MC_ACT_* */
+} mc_conv_prologue;
+
+/* Input-gradient epilogue: the launch computes dA (gradient w.r.t. the ACTIVATED tensor a = act(GN(y))) on the padded
+ * domain; with an epilogue it stores dz = dA * act'(z), z = scale*y + shift, instead and emits the per-tile partial
+ * sums (sum dz, sum dz * yhat) per channel that GroupNorm's backward needs — the separate reduction pass over (dA, y)
+ * disappears.  With reflect / replicate padding the pixels within pad+1 of the border still await the padding adjoint:
+ * they are stored as raw dA and finished (fold + dz + their partial sums) by mc_fold_padded_dz. */
+typedef struct {
+  const void* y;      /* raw conv output of the layer that produced the tensor: CB8 [n][c8][hs][ws], dtype of the desc */
+  const float* coef;  /* its (scale, shift, mean, rstd) table, or NULL for an activation-only layer */
+  int32_t act;        /* MC_ACT_* */
+  int32_t pad;        /* p of the forward conv: the interior starts at (p, p) of the padded-domain output */
+  int32_t pad_mode;   /* MC_PAD_* of the forward conv */
+  int32_t hs, ws;     /* interior (unpadded) size */
+  float* partials;    /* [n][part_stride][c8*8][2] f32; this launch fills slots 0 .. mc_conv_tiles(desc) - 1 of a sample */
+  int32_t part_stride;/* slots per sample (>= tiles; the slots behind the tiles are mc_fold_padded_dz's) */
+} mc_conv_epilogue;
+
 int mc_version(void);
 const char* mc_strerror(int code);
 
@@ -120,6 +147,12 @@ int32_t mc_conv_tiles(const mc_conv_desc* d);
  * taken from the f32 accumulators — the first half of GroupNorm (FluidLayer :788). */
 int mc_conv2d(const mc_conv_desc* d, const void* x0, const void* x1, const void* packed_w,
               const float* bias, void* y0, void* y1, float* stat_partials, void* stream);
+/* The same convolution with the producer's GroupNorm + activation applied to its sources on load (pro, nullable) and,
+ * for an input-gradient launch, the GroupNorm-backward reduction fused into the epilogue (epi, nullable; needs a
+ * single-source, unsplit output).  FluidLayer.forward :790-799 and its autograd backward. */
+int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const mc_conv_prologue* pro,
+                    const void* packed_w, const float* bias, void* y0, void* y1, float* stat_partials,
+                    const mc_conv_epilogue* epi, void* stream);
 /* Filter/bias gradient.  partials: workspace of mc_wgrad_partial_bytes(d); the second call
  * reduces it deterministically, folds mirrored filters back onto the unique bank
  * (dW_unique[i] += flip_x(dW_full[U+i])) and ACCUMULATES into dw_unique / dbias. */
@@ -128,6 +161,9 @@ int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const
                     void* partials, void* stream);
 int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float* dw_unique,
                              float* dbias, void* stream);
+/* mc_conv2d_wgrad with x0 / x1 given as RAW conv outputs: the activation is re-applied on load (pro as in mc_conv2d_fused). */
+int mc_conv2d_wgrad_fused(const mc_conv_desc* d, const void* x0, const void* x1, const mc_conv_prologue* pro,
+                          const void* dy, void* partials, void* stream);
 /* Batched forms (one launch for many layers; per-layer tables are plain host arrays of length n):
  * the per-step bank packing and the filter-gradient combine are tiny per layer and latency-bound when
  * launched one layer at a time. */
@@ -142,6 +178,13 @@ int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* cons
  * touches only the O(p (H+W)) border pixels. */
 int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode,
                    int32_t dtype, void* stream);
+/* Companion of mc_conv2d_fused's epilogue for reflect / replicate padding: folds the halo onto the frame pixels (within
+ * pad+1 of the border) like mc_fold_padded, then turns them into dz = dA * act'(z) in place and writes their partial sums
+ * into `partials` [n][mc_fold_blocks()][c8*8][2] (the caller passes the slots behind the conv tiles' of the same table). */
+int32_t mc_fold_blocks(int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode);
+int mc_fold_padded_dz(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode,
+                      int32_t dtype, const void* y, const float* coef, int32_t act, float* partials,
+                      int32_t part_stride_blocks, int32_t part_first_block, void* stream);
 
 /* ---- GroupNorm + activation (FluidLayer :788-799; Unet :2016-2021) ------------------------ */
 /* Per-tile (sum, sum of squares) partials [n][tiles][ceil(c/8)*8][2] of an existing CB8 tensor, for layers whose output is
@@ -152,6 +195,10 @@ int mc_gn_partials(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, in
  * per-(n,c) means of y when chan_mean != NULL (Unet's spatial zero-mean, :2024). */
 int mc_gn_finalize(const float* stat_partials, int32_t n, int32_t tiles, int32_t c, int32_t groups,
                    int32_t hw, float eps, float* stats_ng2, float* chan_mean, void* stream);
+/* mc_gn_finalize + the (scale, shift, mean, rstd) table [n][ceil(c/8)*8][4] that consumers of the raw conv output read
+ * ("normalise on load"): scale = rstd * gamma, shift = beta - mean * rstd * gamma. */
+int mc_gn_finalize_coef(const float* stat_partials, int32_t n, int32_t tiles, int32_t c, int32_t groups, int32_t hw,
+                        float eps, const float* gamma, const float* beta, float* stats_ng2, float* coef4, void* stream);
 /* Traversal direction of the launches that follow (process-wide, read at launch time, so a HIP-graph capture records it per
  * kernel): reverse != 0 makes the batch-streaming kernels (mc_conv2d, mc_conv2d_wgrad in bf16 mode, mc_gn_act_fwd,
  * mc_gn_act_bwd_reduce / _apply) walk their samples / work items from the last to the first.  Results are identical; a
@@ -160,7 +207,8 @@ int mc_gn_finalize(const float* stat_partials, int32_t n, int32_t tiles, int32_t
 int mc_set_direction(int32_t reverse);
 
 /* a = act(GN(y));  post = MC_POST_*.  pool > 1 additionally writes AvgPool2d(pool)(a) into
- * pooled (Unet :2002, ConvAE :1051).  y, a, pooled are CB8 of `dtype`. */
+ * pooled (Unet :2002, ConvAE :1051).  y, a, pooled are CB8 of `dtype`.  a may be NULL when pool > 1: only the pooled
+ * tensor is materialised (the full-resolution consumers normalise y on load). */
 int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                   const float* stats_ng2, const float* gamma, const float* beta, int32_t post,
                   int32_t act, int32_t pool, int32_t dtype, void* a, void* pooled, void* stream);
@@ -179,6 +227,11 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
                         const float* stats_ng2, const float* m12_ng2, const float* gamma,
                         const float* beta, int32_t post, int32_t act, int32_t dtype,
                         const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream);
+/* Phase 3 for a tensor whose dz = dA * act'(z) was already written by mc_conv2d_fused's epilogue (+ mc_fold_padded_dz):
+ * dy = scale * dz - rstd (m1 + yhat m2)  (coef = the layer's table, m12 from mc_gn_act_bwd_finalize); with coef == NULL
+ * (activation-only layer) dy = dz.  dz is read through a gradient source (MC_GSRC_PADFOLD or MC_GSRC_PLAIN). */
+int mc_gn_bwd_apply_dz(const mc_grad_src* dz, const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                       const float* coef, const float* m12_ng2, int32_t dtype, void* dy, void* stream);
 /* Phases 2 + 3 in one launch: every workgroup re-derives its groups' (m1, m2) from the phase-1 partials
  * (blocks x channels, L2-resident) and the first workgroup of each (n, channel block) accumulates dgamma/dbeta. */
 int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
@@ -209,6 +262,11 @@ int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, in
 int mc_bicubic_fwd(const void* x, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                    const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x, const float* wgt_x,
                    int32_t dtype, void* out, void* stream);
+/* mc_bicubic_fwd of act(scale * x + shift): x is a raw conv output, activated while the input window is staged
+ * (coef nullable = activation only). */
+int mc_bicubic_fwd_act(const void* x, const float* coef, int32_t act, int32_t n, int32_t c, int32_t hi, int32_t wi,
+                       int32_t ho, int32_t wo, const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x,
+                       const float* wgt_x, int32_t dtype, void* out, void* stream);
 /* adjoint: transposed tap tables in CSR form per axis (start [in+1], j [], w []). */
 int mc_bicubic_bwd(const mc_grad_src* g, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                    const int32_t* ty_start, const int32_t* ty_j, const float* ty_w,

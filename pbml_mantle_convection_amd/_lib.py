@@ -29,6 +29,17 @@ class GradSrc(C.Structure):
                 ("pool", C.c_int32), ("hs", C.c_int32), ("ws", C.c_int32), ("c8_total", C.c_int32), ("cb_off", C.c_int32)]
 
 
+class ConvPrologue(C.Structure):
+    """mc_conv_prologue: GroupNorm affine + activation of the producer, applied by the consumer on load."""
+    _fields_ = [("coef0", C.c_void_p), ("coef1", C.c_void_p), ("act0", C.c_int32), ("act1", C.c_int32)]
+
+
+class ConvEpilogue(C.Structure):
+    """mc_conv_epilogue: dz = dA * act'(z) + GroupNorm-backward partial sums in the input-gradient launch."""
+    _fields_ = [("y", C.c_void_p), ("coef", C.c_void_p), ("act", C.c_int32), ("pad", C.c_int32), ("pad_mode", C.c_int32),
+                ("hs", C.c_int32), ("ws", C.c_int32), ("partials", C.c_void_p), ("part_stride", C.c_int32)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("p_pred", C.c_int32),
                 ("loss_type", C.c_int32), ("loss_scale", C.c_int32), ("loss_derivative", C.c_int32),
@@ -38,6 +49,7 @@ class LossDesc(C.Structure):
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _CD, _GS, _LD = C.POINTER(ConvDesc), C.POINTER(GradSrc), C.POINTER(LossDesc)
+_CP, _CE = C.POINTER(ConvPrologue), C.POINTER(ConvEpilogue)
 
 # name -> (restype, argtypes); must list EVERY symbol include/mantle_hip.h declares
 SIGNATURES = {
@@ -53,6 +65,14 @@ SIGNATURES = {
     "mc_conv_tiles": (_i32, [_CD]),
     "mc_conv_kernel_name": (C.c_char_p, [_CD]),
     "mc_conv2d": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_conv2d_fused": (C.c_int, [_CD, _vp, _vp, _CP, _vp, _vp, _vp, _vp, _vp, _CE, _vp]),
+    "mc_conv2d_wgrad_fused": (C.c_int, [_CD, _vp, _vp, _CP, _vp, _vp, _vp]),
+    "mc_gn_finalize_coef": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "mc_fold_blocks": (_i32, [_i32, _i32, _i32, _i32]),
+    "mc_fold_padded_dz": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "mc_gn_bwd_apply_dz": (C.c_int, [_GS, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "mc_bicubic_fwd_act": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
+                                     _vp]),
     "mc_wgrad_partial_bytes": (_sz, [_CD]),
     "mc_conv2d_wgrad": (C.c_int, [_CD, _vp, _vp, _vp, _vp, _vp]),
     "mc_conv2d_wgrad_finalize": (C.c_int, [_CD, _vp, _vp, _vp, _vp]),
@@ -99,7 +119,7 @@ SIGNATURES = {
 
 # entry points whose return value is a quantity, not a status code
 VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_conv_kernel_name", "mc_packed_weight_bytes", "mc_conv_tiles",
-                   "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks"}
+                   "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks", "mc_fold_blocks"}
 
 _lib = None
 

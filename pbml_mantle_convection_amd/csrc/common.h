@@ -207,6 +207,38 @@ __device__ __forceinline__ void act_bwd8(const float (&v)[8], const float (&sc)[
 template <typename T> struct FastMath { static constexpr bool value = false; };
 template <> struct FastMath<bf16_t> { static constexpr bool value = true; };
 
+// ---- GroupNorm + activation applied by the CONSUMER of a raw conv output ("normalise on load") -----------------
+// coef4: [n][CP][4] f32 = (scale, shift, mean, rstd) per (sample, channel), written by mc_gn_finalize_coef with the
+// same f32 expressions gn_coef() uses (scale = rstd * gamma, shift = beta - mean * rstd * gamma), so a consumer that
+// evaluates act(scale * y + shift) obtains bit-identical values to the stand-alone mc_gn_act_fwd pass.  Padded channels
+// hold zeros (act(0) = 0 for every supported activation).  A NULL table means "activation only" (scale 1, shift 0).
+// The (n, channel block) of a staged tile is workgroup-uniform, so these loads go through the scalar cache.
+__device__ __forceinline__ void load_coef8(const float* __restrict__ coef4, int n, int CP, int cb, float (&sc)[8], float (&sh)[8]) {
+  if (coef4) {
+    const float4* p = reinterpret_cast<const float4*>(coef4) + (size_t)n * CP + cb * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float4 v = p[j]; sc[j] = v.x; sh[j] = v.y; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+  }
+}
+// one CB8 vector (8 channels of one pixel): raw conv output -> activated value, in the storage type
+__device__ __forceinline__ uint4 xform_bf16x8(uint4 a, const float (&sc)[8], const float (&sh)[8], int act) {
+  float v[8];
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  act_fwd8<true>(v, sc, sh, act, v);
+  uint4 o;
+  o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  return o;
+}
+
 // ---- wave / block reductions (wave = 64) --------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

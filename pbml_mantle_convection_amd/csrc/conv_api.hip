@@ -2,15 +2,17 @@
 #include "conv_common.h"
 
 int mc_conv2d_f32(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
-                  void* y1, float* part, hipStream_t s);
-int mc_wgrad_f32(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s);
+                  void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s);
+int mc_wgrad_f32(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, const ConvFuse& fz, int fuse,
+                 hipStream_t s);
 // bf16 MFMA path (conv_bf16.hip)
 int mc_bf16_tile(const mc_conv_desc* d, int* th, int* tw);
 size_t mc_bf16_bank_bytes(const ConvGeom& g, int dgrad);
 int mc_bf16_pack(const ConvGeom& g, const float* w_unique, int dgrad, void* packed, hipStream_t s);
 int mc_conv2d_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
-                   void* y1, float* part, hipStream_t s);
-int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s);
+                   void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s);
+int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, const ConvFuse& fz, int fuse,
+                  hipStream_t s);
 const char* mc_bf16_kernel_name(const ConvGeom& g);
 void mc_bf16_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles);
 
@@ -200,14 +202,47 @@ int32_t mc_conv_tiles(const mc_conv_desc* d) {
   return g.tiles;
 }
 
-int mc_conv2d(const mc_conv_desc* d, const void* x0, const void* x1, const void* packed_w, const float* bias, void* y0,
-              void* y1, float* stat_partials, void* stream) {
+static bool act_ok(int a) { return a >= MC_ACT_NONE && a <= MC_ACT_ELU; }
+
+// fills the prologue half of fz; returns 1 when a source really needs the transform
+static int fill_prologue(const mc_conv_prologue* pro, ConvFuse& fz, int& rc) {
+  rc = MC_OK;
+  if (!pro) return 0;
+  if (!act_ok(pro->act0) || !act_ok(pro->act1)) { rc = MC_EINVAL; return 0; }
+  fz.coef0 = pro->coef0; fz.coef1 = pro->coef1; fz.act0 = pro->act0; fz.act1 = pro->act1;
+  return (pro->coef0 || pro->coef1 || pro->act0 != MC_ACT_NONE || pro->act1 != MC_ACT_NONE) ? 1 : 0;
+}
+
+int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const mc_conv_prologue* pro,
+                    const void* packed_w, const float* bias, void* y0, void* y1, float* stat_partials,
+                    const mc_conv_epilogue* epi, void* stream) {
   ConvGeom g;
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!x0 || !packed_w || !y0 || (g.Cin1 > 0 && !x1) || (g.split8 > 0 && !y1)) return MC_EINVAL;
-  if (g.dtype == MC_BF16) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, (hipStream_t)stream);
-  return mc_conv2d_f32(g, x0, x1, packed_w, bias, y0, y1, stat_partials, (hipStream_t)stream);
+  ConvFuse fz = conv_fuse_none();
+  int fuse = fill_prologue(pro, fz, rc);
+  if (rc) return rc;
+  if (epi) {
+    // input-gradient launch on the padded domain of a (hs x ws) tensor with a single, unsplit output
+    if (fuse) return MC_EUNSUPPORTED;                       // (the gradient tensor dY is never a raw conv output)
+    if (!epi->y || !epi->partials || !act_ok(epi->act) || epi->pad < 0 || epi->hs <= 0 || epi->ws <= 0) return MC_EINVAL;
+    if (epi->pad_mode < MC_PAD_ZEROS || epi->pad_mode > MC_PAD_REFLECT) return MC_EINVAL;
+    if (g.split8 > 0 || stat_partials || g.out_f32) return MC_EUNSUPPORTED;
+    if (g.Ho != epi->hs + 2 * epi->pad || g.Wo != epi->ws + 2 * epi->pad) return MC_EINVAL;
+    fz.ey = epi->y; fz.ecoef = epi->coef; fz.epart = epi->partials; fz.eact = epi->act; fz.epad = epi->pad;
+    fz.ezero = epi->pad_mode == MC_PAD_ZEROS || epi->pad == 0; fz.ehs = epi->hs; fz.ews = epi->ws;
+    if (epi->part_stride < g.tiles) return MC_EINVAL;
+    fz.estride = epi->part_stride;
+    fuse = 2;
+  }
+  if (g.dtype == MC_BF16) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
+  return mc_conv2d_f32(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
+}
+
+int mc_conv2d(const mc_conv_desc* d, const void* x0, const void* x1, const void* packed_w, const float* bias, void* y0,
+              void* y1, float* stat_partials, void* stream) {
+  return mc_conv2d_fused(d, x0, x1, nullptr, packed_w, bias, y0, y1, stat_partials, nullptr, stream);
 }
 
 size_t mc_wgrad_partial_bytes(const mc_conv_desc* d) {
@@ -216,14 +251,22 @@ size_t mc_wgrad_partial_bytes(const mc_conv_desc* d) {
   return (size_t)g.wgrad_G * wg_slab_floats(g.CoutP, g.CinP, g.K * g.K) * sizeof(float);
 }
 
-int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const void* dy, void* partials,
-                    void* stream) {
+int mc_conv2d_wgrad_fused(const mc_conv_desc* d, const void* x0, const void* x1, const mc_conv_prologue* pro,
+                          const void* dy, void* partials, void* stream) {
   ConvGeom g;
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!x0 || !dy || !partials || (g.Cin1 > 0 && !x1)) return MC_EINVAL;
-  if (g.dtype == MC_BF16) return mc_wgrad_bf16(g, x0, x1, dy, partials, (hipStream_t)stream);
-  return mc_wgrad_f32(g, x0, x1, dy, partials, (hipStream_t)stream);
+  ConvFuse fz = conv_fuse_none();
+  const int fuse = fill_prologue(pro, fz, rc);
+  if (rc) return rc;
+  if (g.dtype == MC_BF16) return mc_wgrad_bf16(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
+  return mc_wgrad_f32(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
+}
+
+int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const void* dy, void* partials,
+                    void* stream) {
+  return mc_conv2d_wgrad_fused(d, x0, x1, nullptr, dy, partials, stream);
 }
 
 int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* const* partials, float* const* dw,

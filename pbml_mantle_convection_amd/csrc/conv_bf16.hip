@@ -71,14 +71,16 @@ __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad,
 #else
 #define MC_SYNC() __syncthreads()
 #endif
-template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false>
+// FUSE: 0 = plain; 1 = prologue (the sources are raw conv outputs: GroupNorm affine + activation applied while the tile
+// is staged); 2 = input-gradient epilogue (dz = dA * act'(z) and the GroupNorm-backward partial sums instead of dA).
+template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false, int FUSE = 0>
 #ifndef MC_CONV_WAVES
 #define MC_CONV_WAVES 2
 #endif
 __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_conv_mfma_bf16(
     ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ bank,
     const float* __restrict__ bias, bf16_t* __restrict__ y0, bf16_t* __restrict__ y1, float* __restrict__ part,
-    int n_groups) {
+    int n_groups, ConvFuse fz) {
   constexpr int TIH = TH + K - 1, TIW = TW + K - 1;
   constexpr int PLANE = (TIH * TIW + 15) / 16 * 16;           // 16-byte slots per channel-block plane
   constexpr int STEPS = KSteps<K>::steps;
@@ -120,6 +122,11 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   constexpr int PER_CB = (TIH * TIW + NTHR - 1) / NTHR;
   static_assert(IN_ITERS <= CHUNK_CB * PER_CB, "");
   v4u rin[CHUNK_CB][PER_CB];
+  // FUSE == 1: per staged channel block the producer's (scale, shift) of its 8 channels (workgroup-uniform: scalar
+  // loads), its activation (-1: the block is used as it is) and the slots that are zero padding (bit it of okm clear)
+  float psc[CHUNK_CB][8], psh[CHUNK_CB][8];
+  int pact[CHUNK_CB] = {-1, -1};
+  unsigned okm = 0xffffffffu;
   int s_rc[PER_CB];                                             // window (row, col) of this thread's slot; bit 31: dead
   unsigned s_off[PER_CB];                                       // byte offset of the slot inside an interior tile's window
   int s_lds[PER_CB];                                            // LDS slot (negative: dead)
@@ -151,6 +158,13 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
       const char* pbase = reinterpret_cast<const char*>(second ? x1 : x0) + ((size_t)n * sC8 + scb) * plane_bytes;
       // records = one channel-block plane; a missing block (gcb >= CBin) gets an empty descriptor -> all zeros
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, gcb < g.CBin ? (int)plane_bytes : 0, 0x00020000);
+      if constexpr (FUSE == 1) {
+        const float* ct = second ? fz.coef1 : fz.coef0;
+        const int a = second ? fz.act1 : fz.act0;
+        pact[cb] = (gcb < g.CBin && (ct != nullptr || a != MC_ACT_NONE)) ? a : -1;
+        if (pact[cb] >= 0) load_coef8(ct, n, sC8 * 8, scb, psc[cb], psh[cb]);
+        if (cb == 0) okm = 0xffffffffu;
+      }
 #pragma unroll
       for (int it = 0; it < PER_CB; ++it) {
         unsigned off;
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
           int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
           int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
           off = (oky && okx) ? (unsigned)(sy * g.W + sx) * 16u : 0xFFFFFFF0u;
+          if (FUSE == 1 && cb == 0 && !(oky && okx)) okm &= ~(1u << it);
         }
 #ifdef MC_EXP_NOLOAD   /* timing experiment only: wrong results */
         rin[cb][it] = (v4u){off, off, off, off};
@@ -173,11 +188,23 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int cb = 0; cb < CHUNK_CB; ++cb)
+    for (int cb = 0; cb < CHUNK_CB; ++cb) {
+      if (FUSE == 1 && pact[cb] >= 0) {
+        // normalise on load: a = act(scale * y + shift) in the storage type; zero padding stays zero
+#pragma unroll
+        for (int it = 0; it < PER_CB; ++it)
+          if (s_lds[it] >= 0) {
+            uint4 v = xform_bf16x8(make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]), psc[cb], psh[cb], pact[cb]);
+            if (!((okm >> it) & 1u)) v = make_uint4(0, 0, 0, 0);
+            in_s[cb * PLANE + s_lds[it]] = v;
+          }
+        continue;
+      }
 #pragma unroll
       for (int it = 0; it < PER_CB; ++it)
         if (s_lds[it] >= 0)
           in_s[cb * PLANE + s_lds[it]] = make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]);
+    }
   };
   // the bank slice changes only with the chunk: single-chunk layers (65 % of the FLOPs) stage it once
   auto stage_weights = [&](int ck) {
@@ -373,8 +400,71 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
         }
       }
     };
-    if (ty0 + TH <= g.Ho && tx0 + TW <= g.Wo) emit(std::true_type{}); else emit(std::false_type{});
+    // FUSE == 2 (input gradient with the GroupNorm-backward reduction fused in): the accumulators hold dA, the gradient
+    // w.r.t. the ACTIVATED tensor a = act(z), z = scale * y + shift, on the padded domain.  Pixels whose value is final
+    // (interior; with reflect / replicate padding only those farther than pad from the border — the frame still awaits
+    // the padding adjoint, mc_fold_padded_dz finishes it) are stored as dz = dA * act'(z) and enter the per-tile
+    // (sum dz, sum dz * yhat) partials; every other pixel is stored as raw dA.
+    auto emit_dz = [&]() {
+      const int p = fz.epad, fr = fz.ezero ? 0 : p + 1;
+      const int CBe = g.CBout;                                    // channel blocks of the producer's output = ours
+      const bf16_t* ey = reinterpret_cast<const bf16_t*>(fz.ey);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int cob = (ntile0 + tt) * 2 + (gq >> 1);
+        const int cbc = min(cob, g.CBout - 1);
+        // (scale, shift, mean, rstd) of this lane's four channels
+        float csc[4], csh[4], cme[4], crs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (fz.ecoef) {
+            const float4 c4 = reinterpret_cast<const float4*>(fz.ecoef)[(size_t)n * g.CoutP + cbc * 8 + (gq & 1) * 4 + r];
+            csc[r] = c4.x; csh[r] = c4.y; cme[r] = c4.z; crs[r] = c4.w;
+          } else { csc[r] = 1.f; csh[r] = 0.f; cme[r] = 0.f; crs[r] = 0.f; }
+        }
+        uint2 yv[MT];
+        bool fin[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int iy = oy0 + i / MTILES_X - p, ix = ox0 + (i % MTILES_X) * 16 - p;
+          fin[i] = cobok[tt] && iy >= fr && iy < fz.ehs - fr && ix >= fr && ix < fz.ews - fr;
+          const int cy = min(max(iy, 0), fz.ehs - 1), cx = min(max(ix, 0), fz.ews - 1);
+          yv[i] = *reinterpret_cast<const uint2*>(ey + cb8_index(n, cbc, cy, cx, CBe, fz.ehs, fz.ews) + (gq & 1) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int oy = oy0 + i / MTILES_X, ox = ox0 + (i % MTILES_X) * 16;
+          const bool inb = oy < g.Ho && ox < g.Wo;
+          const size_t off = (size_t)(i / MTILES_X) * row_bytes + (size_t)(i % MTILES_X) * 16 * 8 * 2;
+          const float yf[4] = {__uint_as_float(yv[i].x << 16), __uint_as_float(yv[i].x & 0xffff0000u),
+                               __uint_as_float(yv[i].y << 16), __uint_as_float(yv[i].y & 0xffff0000u)};
+          float o[4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 yy = (f32x2){yf[2 * h], yf[2 * h + 1]};
+            const f32x2 z = pk_fma(yy, (f32x2){csc[2 * h], csc[2 * h + 1]}, (f32x2){csh[2 * h], csh[2 * h + 1]});
+            f32x2 gp;
+            if (fz.eact == MC_ACT_GELU) gp = gelu_grad_poly2(z);
+            else gp = (f32x2){act_bwd(z.x, fz.eact), act_bwd(z.y, fz.eact)};
+            const f32x2 da = (f32x2){acc[i][tt][2 * h], acc[i][tt][2 * h + 1]};
+            const f32x2 dz = da * gp;
+            const f32x2 yh = (yy - (f32x2){cme[2 * h], cme[2 * h + 1]}) * (f32x2){crs[2 * h], crs[2 * h + 1]};
+            if (fin[i]) { s1[tt][h] += dz; s2[tt][h] = pk_fma(dz, yh, s2[tt][h]); }
+            o[2 * h] = fin[i] ? dz.x : da.x; o[2 * h + 1] = fin[i] ? dz.y : da.y;
+          }
+          if (inb && cobok[tt]) {
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+            pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+            *reinterpret_cast<uint2*>(dst0[tt] + off) = pk;
+          }
+        }
+      }
+    };
+    if constexpr (FUSE == 2) emit_dz();
+    else { if (ty0 + TH <= g.Ho && tx0 + TW <= g.Wo) emit(std::true_type{}); else emit(std::false_type{}); }
     STAMP(5);
+    if (FUSE == 2) part = fz.epart;
     if (part) {
       // sum over the 16 pixel lanes of each 16-lane group with a halving butterfly (8 shuffles for the 8 values of an
       // N-tile instead of 32): afterwards lane m of a group holds the group total of value index m >> 1 (m even)
@@ -399,7 +489,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
           float r = 0.f;
 #pragma unroll
           for (int wv = 0; wv < WAVES; ++wv) r += red[wv][threadIdx.x];
-          part[(((size_t)n * g.tiles + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
+          part[(((size_t)n * (FUSE == 2 ? fz.estride : g.tiles) + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
         }
       }
     }
@@ -447,10 +537,11 @@ constexpr int WTH = 16, WTW = 32;      // work-item tile (output pixels)
 // wave / RS of RS 8-column blocks).  RS 1: all taps + bias, one column block (26 NTW accumulators); RS 2: 13/12 taps,
 // two column blocks; RS 4: 7/6/6/6 taps, the whole tile (no cross-wave sum).  The bias gradient rides in the spare
 // slot of the last tap group.  Column groups are summed through LDS once per workgroup.
-template <int K, int NTW, int RS>
+// PRO: x0 / x1 are raw conv outputs; the producer's GroupNorm affine + activation are applied while the tile is staged.
+template <int K, int NTW, int RS, bool PRO = false>
 __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
                                                             const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
-                                                            float* __restrict__ part, int tiles_x, int tiles) {
+                                                            float* __restrict__ part, int tiles_x, int tiles, ConvFuse fz) {
   static_assert(RS == 0 || RS == 1 || RS == 2 || RS == 4, "tap groups");
   constexpr int NS = RS ? RS : 1;                               // tap groups
   constexpr int NG = 4 / NS;                                    // column groups (waves that share a tap group)
@@ -467,7 +558,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
                 "register-shift LDS layout");
   constexpr int NTAP = (KK + 3) / 4;                          // taps per wave (upper bound)
   constexpr int NACC = RS ? TPW * NTW : NTAP * NTW;            // [tap slot (+ bias)][co tile]
-  constexpr int X_ELEMS = 2 * TIH * TIW, X_ITERS = (X_ELEMS + 255) / 256;
+  constexpr int X_ITERS = (TIH * TIW + 255) / 256;            // staging slots per thread and channel-block plane
   constexpr int D_ELEMS = NTW * 2 * WTH * WTW, D_ITERS = D_ELEMS / 256;
   static_assert(D_ELEMS % 256 == 0, "dy tile must divide evenly over the threads");
   __shared__ uint4 smem[2 * XPS + NTW * 2 * DPS];
@@ -501,18 +592,18 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
   const short* xtap[NTAP];                                      // this lane's x-tile address per tap (row 0)
 #pragma unroll
   for (int ti = 0; ti < NTAP; ++ti) xtap[ti] = xs_s + lane_x + max(toff[ti], 0);
-  // static staging slots of this thread (decoded once: the staging address arithmetic was a third of the kernel's VALU work)
+  // static staging slots of this thread (decoded once: the staging address arithmetic was a third of the kernel's VALU work);
+  // the two channel-block planes of the chunk use the same slots (the plane is uniform per load: scalar base, and the
+  // producer's normalisation coefficients of a plane are uniform too)
   int x_rc[X_ITERS];
   unsigned x_off[X_ITERS];
 #pragma unroll
   for (int it = 0; it < X_ITERS; ++it) {
     int i = threadIdx.x + it * 256;
-    bool live = i < X_ELEMS;
-    if (!live) i = X_ELEMS - 1;
-    int cb = i / (TIH * TIW);
-    int rem = i - cb * (TIH * TIW);
-    int r = rem / TIW, c = rem - r * TIW;
-    x_rc[it] = (live ? 0 : (1 << 31)) | (cb << 30) | (r << 15) | c;
+    bool live = i < TIH * TIW;
+    if (!live) i = TIH * TIW - 1;
+    int r = i / TIW, c = i - r * TIW;
+    x_rc[it] = (live ? 0 : (1 << 31)) | (r << 15) | c;
     x_off[it] = (unsigned)(r * g.W + c) * 16u;
   }
   // dy staging: static element offset of this thread's slots inside a (image, co-group) tile that lies fully inside
@@ -538,33 +629,53 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
                 cb8_index(0, second ? gcc - g.CB0 : gcc, 0, 0, xC8[cb], g.H, g.W) * sizeof(bf16_t);
   }
 
-  uint4 rx[X_ITERS], rd[D_ITERS];
+  uint4 rx[2][X_ITERS], rd[D_ITERS];
+  // PRO: (scale, shift) of the 8 channels of each plane for the sample being staged (uniform: scalar loads), the plane's
+  // activation (-1: used as it is), and the slots that are zero padding (bit clear)
+  float psc[2][8], psh[2][8];
+  int pact[2] = {-1, -1};
+  unsigned okm = 0xffffffffu;
   auto prefetch = [&](int wi_fwd) __attribute__((always_inline)) {
     const int wi = g.rev ? g.N * tiles - 1 - wi_fwd : wi_fwd;
     const int n = wi / tiles, tile = wi - n * tiles;
     const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
     const char* bpn[2] = {xbase[0] + (size_t)n * xC8[0] * g.H * g.W * 16, xbase[1] + (size_t)n * xC8[1] * g.H * g.W * 16};
+    if constexpr (PRO) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int gcb = min(chunk * 2 + cb, g.CBin - 1);
+        const bool second = gcb >= g.CB0;
+        const float* ct = second ? fz.coef1 : fz.coef0;
+        const int a = second ? fz.act1 : fz.act0;
+        pact[cb] = (xok[cb] && (ct != nullptr || a != MC_ACT_NONE)) ? a : -1;
+        if (pact[cb] >= 0) load_coef8(ct, n, xC8[cb] * 8, second ? gcb - g.CB0 : gcb, psc[cb], psh[cb]);
+      }
+      okm = 0xffffffffu;
+    }
     if (interior) {
       const size_t org = (size_t)((ty0 - g.pad) * g.W + (tx0 - g.pad)) * 16;
 #pragma unroll
-      for (int it = 0; it < X_ITERS; ++it) {
-        const bool cb1 = ((x_rc[it] >> 30) & 1) != 0;
-        uint4 v = *reinterpret_cast<const uint4*>((cb1 ? bpn[1] : bpn[0]) + org + x_off[it]);
-        rx[it] = (cb1 ? xok[1] : xok[0]) ? v : make_uint4(0, 0, 0, 0);
-      }
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int it = 0; it < X_ITERS; ++it) {
+          uint4 v = *reinterpret_cast<const uint4*>(bpn[cb] + org + x_off[it]);
+          rx[cb][it] = xok[cb] ? v : make_uint4(0, 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int it = 0; it < X_ITERS; ++it) {
         int r = (x_rc[it] >> 15) & 0x7fff, c = x_rc[it] & 0x7fff;
-        bool cb1 = ((x_rc[it] >> 30) & 1) != 0;
-        bool ok = cb1 ? xok[1] : xok[0];
         bool oky, okx;
         int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
         int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
-        ok = ok && oky && okx;
-        uint4 v = *reinterpret_cast<const uint4*>((cb1 ? bpn[1] : bpn[0]) + (size_t)(sy * g.W + sx) * 16);
-        rx[it] = ok ? v : make_uint4(0, 0, 0, 0);
+        const bool ok = oky && okx;
+        if (PRO && !ok) okm &= ~(1u << it);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          uint4 v = *reinterpret_cast<const uint4*>(bpn[cb] + (size_t)(sy * g.W + sx) * 16);
+          rx[cb][it] = (ok && xok[cb]) ? v : make_uint4(0, 0, 0, 0);
+        }
       }
     }
     if (co_full && ty0 + WTH <= g.Ho && tx0 + WTW <= g.Wo) {
@@ -590,12 +701,21 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
   };
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < X_ITERS; ++it)
-    {
-      int v = x_rc[it];
-      asm volatile("" : "+v"(v));               // opaque: keeps the slot decode out of loop-invariant registers
-      if (v >= 0) xs[((v >> 30) & 1) * XPS + ((v >> 15) & 0x7fff) * XRS + (v & 0x7fff)] = rx[it];
-    }
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int it = 0; it < X_ITERS; ++it)
+      {
+        int v = x_rc[it];
+        asm volatile("" : "+v"(v));               // opaque: keeps the slot decode out of loop-invariant registers
+        if (v >= 0) {
+          uint4 q = rx[cb][it];
+          if (PRO && pact[cb] >= 0) {
+            q = xform_bf16x8(q, psc[cb], psh[cb], pact[cb]);
+            if (!((okm >> it) & 1u)) q = make_uint4(0, 0, 0, 0);
+          }
+          xs[cb * XPS + ((v >> 15) & 0x7fff) * XRS + (v & 0x7fff)] = q;
+        }
+      }
 #pragma unroll
     for (int it = 0; it < D_ITERS; ++it) ds[d_lds0 + (it >> 1) * DPS + 8 * (it & 1) * DRS] = rd[it];
   };
@@ -837,7 +957,7 @@ const char* mc_bf16_kernel_name(const ConvGeom& g) {
 }
 
 int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
-                   void* y1, float* part, hipStream_t s) {
+                   void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s) {
   ConvGeom g = g_in;
   g.rev = mc_g_reverse;
   Bf16Cfg c = cfg_for(g.Cout);
@@ -848,25 +968,31 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
   int cap = cap_total / groups > 0 ? cap_total / groups : 1;     // persistent: a few resident workgroups per CU, several items each
   int bx = items < cap ? items : cap;
   dim3 grid(bx, groups, 1);
-#define LAUNCH(K, TH, TW, NT, MT)                                                                                    \
-  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT>), grid, dim3(64 * (TH * (TW / 16) / MT)), 0, s, g, (const bf16_t*)x0, \
-                     (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups)
+  if (fuse == 2 && g.out_f32) return MC_EUNSUPPORTED;
+#define LAUNCH_F(K, TH, TW, NT, MT, F32, FU)                                                                           \
+  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT, F32, FU>), grid, dim3(64 * (TH * (TW / 16) / MT)), 0, s, g,  \
+                     (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part,  \
+                     groups, fz)
+#define LAUNCH(K, TH, TW, NT, MT, F32)                                                                                 \
+  do { if (fuse == 0) LAUNCH_F(K, TH, TW, NT, MT, F32, 0); else if (fuse == 1) LAUNCH_F(K, TH, TW, NT, MT, F32, 1);   \
+       else LAUNCH_F(K, TH, TW, NT, MT, false, 2); } while (0)
   if (g.out_f32) {
-    if (g.K == 5) hipLaunchKernelGGL((k_conv_mfma_bf16<5, 16, 32, 1, MC_NT1_MT, true>), grid, dim3(64 * 32 / MC_NT1_MT), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
-    else hipLaunchKernelGGL((k_conv_mfma_bf16<3, 16, 32, 1, MC_NT1_MT, true>), grid, dim3(64 * 32 / MC_NT1_MT), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, groups);
+    if (g.K == 5) LAUNCH(5, 16, 32, 1, MC_NT1_MT, true); else if (g.K == 3) LAUNCH(3, 16, 32, 1, MC_NT1_MT, true); else return MC_EUNSUPPORTED;
   } else if (g.K == 5) {
-    if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT); else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4); else LAUNCH(5, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH(5, 16, 16, 4, 4, false);
   } else if (g.K == 3) {
-    if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4); else LAUNCH(3, 16, 16, 4, 4);
+    if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4, false); else LAUNCH(3, 16, 16, 4, 4, false);
   } else {
     return MC_EUNSUPPORTED;
   }
 #undef LAUNCH
+#undef LAUNCH_F
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
 
-int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s) {
+int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* dy, void* part, const ConvFuse& fz,
+                  int fuse, hipStream_t s) {
   ConvGeom g = g_in;
   g.rev = mc_g_reverse;
   const int tiles_x = (g.Wo + WTW - 1) / WTW, tiles_y = (g.Ho + WTH - 1) / WTH;
@@ -874,9 +1000,10 @@ int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const vo
   const int ntiles = (g.Cout + 15) / 16;
   const int ntw = pick_nt(ntiles) >= 2 ? 2 : 1;      // two co-tiles per block keep LDS at 55 KB (2-3 blocks per CU)
   dim3 grid(g.wgrad_G, (g.CBin + 1) / 2, (ntiles + ntw - 1) / ntw);
-#define WLAUNCH(K, NTW, RS)                                                                                          \
-  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW, RS>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, \
-                     (const bf16_t*)dy, (float*)part, tiles_x, tiles)
+#define WLAUNCH_P(K, NTW, RS, PRO)                                                                                     \
+  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW, RS, PRO>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, \
+                     (const bf16_t*)dy, (float*)part, tiles_x, tiles, fz)
+#define WLAUNCH(K, NTW, RS) do { if (fuse) WLAUNCH_P(K, NTW, RS, true); else WLAUNCH_P(K, NTW, RS, false); } while (0)
   // A/B knob: two decimal digits = tap groups for (one co-tile, two co-tiles); 0 = the row-at-a-time kernel.  Measured
   // alone at level 0 (16->16, 32x506x512): 0: 266 us, 1: 171, 2: 203, 4: 155; 64->64 at 63x64: 0: 44 us, 4: 37.  Inside
   // the training step 10 / 14 / 44 are equal (the filter gradients run on the side stream and are off the critical path).
@@ -888,6 +1015,7 @@ int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const vo
   else return MC_EUNSUPPORTED;
 #undef WPICK
 #undef WLAUNCH
+#undef WLAUNCH_P
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -17,6 +17,25 @@ struct ConvGeom {
   int out_f32;
 };
 
+// Device-side view of mc_conv_prologue / mc_conv_epilogue (include/mantle_hip.h): what a conv launch fuses on its input
+// side (GroupNorm affine + activation of the producer, applied while the tile is staged) and, for an input-gradient
+// launch, on its output side (dz = dA * act'(z) + the GroupNorm-backward partial sums).
+struct ConvFuse {
+  const float* coef0; const float* coef1;   // (scale, shift, mean, rstd) tables of source 0 / 1, or NULL
+  int act0, act1;                           // MC_ACT_* per source
+  const void* ey;                           // epilogue: raw conv output of the producer, CB8 [N][CBout][ehs][ews]
+  const float* ecoef;                       // its table or NULL
+  float* epart;                             // [N][tiles][CoutP][2]
+  int eact, epad, ezero, ehs, ews;          // ezero: forward padding was zeros (every interior pixel is final)
+  int estride;                              // slots per sample of epart
+};
+static inline ConvFuse conv_fuse_none() {
+  ConvFuse f;
+  f.coef0 = f.coef1 = nullptr; f.act0 = f.act1 = MC_ACT_NONE;
+  f.ey = nullptr; f.ecoef = nullptr; f.epart = nullptr; f.eact = MC_ACT_NONE; f.epad = 0; f.ezero = 1; f.ehs = f.ews = 0; f.estride = 0;
+  return f;
+}
+
 // filter-gradient partial slab (one per reduction workgroup): P[tap][16-channel input chunk][co][16] f32 followed by
 // the bias gradient [CoutP].  The 16 input channels of a chunk are the fastest axis so that the 16-lane groups of
 // the MFMA accumulator layout store 64 contiguous bytes (a [co][ci][tap] layout scattered 4-byte stores 100 B

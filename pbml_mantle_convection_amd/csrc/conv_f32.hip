@@ -14,11 +14,13 @@ constexpr int TS = 16;  // output tile edge
 // block = 16x16 output pixels x 16 output channels; loops over 8-channel input blocks.
 // Bank layout (f32): [cbin][tap][ci8][CoutP]; indices are wave-uniform -> scalar loads.
 // ------------------------------------------------------------------------------------------------
-template <int K>
+// FUSE: 0 plain; 1 = sources are raw conv outputs, normalised + activated while staged (exact erf / exp forms);
+// 2 = input-gradient epilogue (dz = dA * act'(z) + GroupNorm-backward partial sums), see ConvFuse.
+template <int K, int FUSE>
 __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float* __restrict__ x0,
                                                          const float* __restrict__ x1, const float* __restrict__ bank,
                                                          const float* __restrict__ bias, float* __restrict__ y0,
-                                                         float* __restrict__ y1, float* __restrict__ part) {
+                                                         float* __restrict__ y1, float* __restrict__ part, ConvFuse fz) {
   constexpr int TI = TS + K - 1;
   __shared__ float xs[TI * TI][8];
   __shared__ float red[4][32];
@@ -36,6 +38,13 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
     const float* src = cb < g.CB0 ? x0 : x1;
     const int scb = cb < g.CB0 ? cb : cb - g.CB0;
     const int sC8 = cb < g.CB0 ? g.CB0 : g.CB1;
+    float psc[8], psh[8];
+    int pact = -1;
+    if (FUSE == 1) {
+      const float* ct = cb < g.CB0 ? fz.coef0 : fz.coef1;
+      const int a = cb < g.CB0 ? fz.act0 : fz.act1;
+      if (ct != nullptr || a != MC_ACT_NONE) { pact = a; load_coef8(ct, n, sC8 * 8, scb, psc, psh); }
+    }
     for (int i = threadIdx.x; i < TI * TI; i += 256) {
       int r = i / TI, c = i % TI;
       int sy = pad_map(ty0 + r - g.pad, g.H, g.pad_mode), sx = pad_map(tx0 + c - g.pad, g.W, g.pad_mode);
@@ -44,12 +53,21 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
         const float* p = src + cb8_index(n, scb, sy, sx, sC8, g.H, g.W);
         a = *reinterpret_cast<const float4*>(p);
         b = *reinterpret_cast<const float4*>(p + 4);
+        if (FUSE == 1 && pact >= 0) {
+          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          act_fwd8<false>(v, psc, psh, pact, v);
+          a = make_float4(v[0], v[1], v[2], v[3]);
+          b = make_float4(v[4], v[5], v[6], v[7]);
+        }
       }
       *reinterpret_cast<float4*>(&xs[i][0]) = a;
       *reinterpret_cast<float4*>(&xs[i][4]) = b;
     }
     __syncthreads();
     const float* wb = bank + (size_t)cb * K * K * 8 * g.CoutP + co0;
+    // the last channel group of a bank whose CoutP is not a multiple of 16 has only 8 columns: clamp the column so the
+    // (unused) upper accumulators never read past the end of the bank
+    const int comax = g.CoutP - 1 - co0;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
@@ -62,11 +80,14 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
-          for (int co = 0; co < 16; ++co) acc[co] = fmaf(v[ci], wt[ci * g.CoutP + co], acc[co]);
+          for (int co = 0; co < 16; ++co) acc[co] = fmaf(v[ci], wt[ci * g.CoutP + min(co, comax)], acc[co]);
       }
   }
 
   const bool valid = oy < g.Ho && ox < g.Wo;
+  float q1[16], q2[16];                                  // per-channel contributions to the tile partials
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { q1[i] = 0.f; q2[i] = 0.f; }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     int cob = cog * 2 + half;
@@ -78,6 +99,31 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
       o[j] = (co < g.Cout) ? acc[half * 8 + j] + (bias ? bias[co] : 0.f) : 0.f;
       acc[half * 8 + j] = o[j];
     }
+    if (FUSE == 2) {
+      // o = dA on the padded domain; final pixels become dz = dA * act'(z) and enter (sum dz, sum dz * yhat)
+      const int p = fz.epad, fr = fz.ezero ? 0 : p + 1;
+      const int iy = oy - p, ix = ox - p;
+      const bool fin = valid && iy >= fr && iy < fz.ehs - fr && ix >= fr && ix < fz.ews - fr;
+      if (fin) {
+        float yv[8];
+        V8<float>::ld(reinterpret_cast<const float*>(fz.ey) + cb8_index(n, cob, iy, ix, g.CBout, fz.ehs, fz.ews), yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float sc = 1.f, sh = 0.f, me = 0.f, rs = 0.f;
+          if (fz.ecoef) {
+            const float4 c4 = reinterpret_cast<const float4*>(fz.ecoef)[(size_t)n * g.CoutP + cob * 8 + j];
+            sc = c4.x; sh = c4.y; me = c4.z; rs = c4.w;
+          }
+          const float dz = o[j] * act_bwd(yv[j] * sc + sh, fz.eact);
+          q1[half * 8 + j] = dz;
+          q2[half * 8 + j] = dz * (yv[j] - me) * rs;
+          o[j] = dz;
+        }
+      }
+    } else if (valid) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { q1[half * 8 + j] = o[j]; q2[half * 8 + j] = o[j] * o[j]; }
+    }
     if (valid) {
       if (g.split8 > 0 && cob >= g.split8)
         V8<float>::st(y1 + cb8_index(n, cob - g.split8, oy, ox, g.CBout - g.split8, g.Ho, g.Wo), o);
@@ -85,12 +131,12 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
         V8<float>::st(y0 + cb8_index(n, cob, oy, ox, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo), o);
     }
   }
+  if (FUSE == 2) part = fz.epart;
   if (part) {
-    // per-tile (sum, sumsq) per output channel, from the f32 results
+    // per-tile partials per output channel, from the f32 results: (sum, sumsq) of y, or (sum dz, sum dz * yhat)
 #pragma unroll
     for (int co = 0; co < 16; ++co) {
-      float v = valid ? acc[co] : 0.f;
-      float s = wave_sum(v), ss = wave_sum(v * v);
+      float s = wave_sum(q1[co]), ss = wave_sum(q2[co]);
       if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][co * 2] = s; red[threadIdx.x >> 6][co * 2 + 1] = ss; }
     }
     __syncthreads();
@@ -98,7 +144,7 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
       int co = co0 + (threadIdx.x >> 1);
       if (co < g.CoutP) {
         float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        part[(((size_t)n * g.tiles + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
+        part[(((size_t)n * (FUSE == 2 ? fz.estride : g.tiles) + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
       }
     }
   }
@@ -111,10 +157,10 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
 // bias gradient of one output channel each (cbin == 0 blocks only).
 // partial layout: [G][CoutP][CinP*K*K + 1]  (last column = bias)
 // ------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool PRO>
 __global__ __launch_bounds__(256) void k_wgrad_direct_f32(ConvGeom g, const float* __restrict__ x0,
                                                           const float* __restrict__ x1, const float* __restrict__ dy,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, ConvFuse fz) {
   constexpr int TI = TS + K - 1;
   __shared__ float xs[TI * TI][8];
   __shared__ float dys[TS * TS][16];
@@ -136,6 +182,13 @@ __global__ __launch_bounds__(256) void k_wgrad_direct_f32(ConvGeom g, const floa
     const int n = wi / g.tiles, tile = wi % g.tiles;
     const int ty0 = (tile / g.tiles_x) * TS, tx0 = (tile % g.tiles_x) * TS;
     __syncthreads();
+    float psc[8], psh[8];
+    int pact = -1;
+    if (PRO) {
+      const float* ct = cb < g.CB0 ? fz.coef0 : fz.coef1;
+      const int a = cb < g.CB0 ? fz.act0 : fz.act1;
+      if (ct != nullptr || a != MC_ACT_NONE) { pact = a; load_coef8(ct, n, sC8 * 8, scb, psc, psh); }
+    }
     for (int i = t; i < TI * TI; i += 256) {
       int r = i / TI, c = i % TI;
       int sy = pad_map(ty0 + r - g.pad, g.H, g.pad_mode), sx = pad_map(tx0 + c - g.pad, g.W, g.pad_mode);
@@ -144,6 +197,12 @@ __global__ __launch_bounds__(256) void k_wgrad_direct_f32(ConvGeom g, const floa
         const float* p = src + cb8_index(n, scb, sy, sx, sC8, g.H, g.W);
         a = *reinterpret_cast<const float4*>(p);
         b = *reinterpret_cast<const float4*>(p + 4);
+        if (PRO && pact >= 0) {
+          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          act_fwd8<false>(v, psc, psh, pact, v);
+          a = make_float4(v[0], v[1], v[2], v[3]);
+          b = make_float4(v[4], v[5], v[6], v[7]);
+        }
       }
       *reinterpret_cast<float4*>(&xs[i][0]) = a;
       *reinterpret_cast<float4*>(&xs[i][4]) = b;
@@ -198,26 +257,27 @@ __global__ __launch_bounds__(256) void k_wgrad_direct_f32(ConvGeom g, const floa
 }  // namespace
 
 int mc_conv2d_f32(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
-                  void* y1, float* part, hipStream_t s) {
+                  void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s) {
   dim3 grid(g.tiles, cdiv(g.CoutP, 16), g.N);
-  if (g.K == 5)
-    hipLaunchKernelGGL(k_conv_direct_f32<5>, grid, dim3(256), 0, s, g, (const float*)x0, (const float*)x1, (const float*)bank, bias, (float*)y0, (float*)y1, part);
-  else if (g.K == 3)
-    hipLaunchKernelGGL(k_conv_direct_f32<3>, grid, dim3(256), 0, s, g, (const float*)x0, (const float*)x1, (const float*)bank, bias, (float*)y0, (float*)y1, part);
-  else
-    return MC_EUNSUPPORTED;
+#define CL(K, FU) hipLaunchKernelGGL((k_conv_direct_f32<K, FU>), grid, dim3(256), 0, s, g, (const float*)x0, (const float*)x1, (const float*)bank, bias, (float*)y0, (float*)y1, part, fz)
+#define CLF(K) do { if (fuse == 0) CL(K, 0); else if (fuse == 1) CL(K, 1); else CL(K, 2); } while (0)
+  if (g.K == 5) CLF(5);
+  else if (g.K == 3) CLF(3);
+  else return MC_EUNSUPPORTED;
+#undef CLF
+#undef CL
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
 
-int mc_wgrad_f32(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, hipStream_t s) {
+int mc_wgrad_f32(const ConvGeom& g, const void* x0, const void* x1, const void* dy, void* part, const ConvFuse& fz, int fuse,
+                 hipStream_t s) {
   dim3 grid(g.wgrad_G, g.CBin, cdiv(g.CoutP, 16));
-  if (g.K == 5)
-    hipLaunchKernelGGL(k_wgrad_direct_f32<5>, grid, dim3(256), 0, s, g, (const float*)x0, (const float*)x1, (const float*)dy, (float*)part);
-  else if (g.K == 3)
-    hipLaunchKernelGGL(k_wgrad_direct_f32<3>, grid, dim3(256), 0, s, g, (const float*)x0, (const float*)x1, (const float*)dy, (float*)part);
-  else
-    return MC_EUNSUPPORTED;
+#define WL(K, PRO) hipLaunchKernelGGL((k_wgrad_direct_f32<K, PRO>), grid, dim3(256), 0, s, g, (const float*)x0, (const float*)x1, (const float*)dy, (float*)part, fz)
+  if (g.K == 5) { if (fuse) WL(5, true); else WL(5, false); }
+  else if (g.K == 3) { if (fuse) WL(3, true); else WL(3, false); }
+  else return MC_EUNSUPPORTED;
+#undef WL
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

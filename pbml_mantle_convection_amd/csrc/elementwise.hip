@@ -165,13 +165,16 @@ __global__ __launch_bounds__(256) void k_gn_partials(const T* __restrict__ y, in
   }
 }
 
-// one wave per (n, g); also optional per-(n,c) means (block g handles its own channels)
+// one wave per (n, g); also optional per-(n,c) means (block g handles its own channels) and the (scale, shift, mean,
+// rstd) table [n][CP][4] read by consumers that normalise the raw conv output on load (same f32 expressions as gn_coef)
 __global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, int CP, int groups, int hw,
-                              float eps, float* __restrict__ stats, float* __restrict__ chan_mean) {
+                              float eps, float* __restrict__ stats, float* __restrict__ chan_mean,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ coef4) {
   const int n = blockIdx.y, g = blockIdx.x;
   const int cpg = C / groups;
   double s = 0.0, ss = 0.0;
-  if (pow2_le64(cpg)) {
+  const bool p2 = pow2_le64(cpg);
+  if (p2) {
     double cs, css;
     group_channel_sums(part, (size_t)n * tiles, tiles, CP, g * cpg, cpg, cs, css);
     const int lane = threadIdx.x & 63;
@@ -193,13 +196,22 @@ __global__ void k_gn_finalize(const float* __restrict__ part, int tiles, int C, 
       ss += css;
     }
   }
+  // every lane holds the group totals
+  const double m = (double)cpg * (double)hw;
+  const double mean = s / m;
+  double var = ss / m - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean, rstdf = (float)(1.0 / sqrt(var + (double)eps));
   if (threadIdx.x == 0 && stats) {
-    double m = (double)cpg * (double)hw;
-    double mean = s / m;
-    double var = ss / m - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((size_t)n * groups + g) * 2 + 0] = (float)mean;
-    stats[((size_t)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[((size_t)n * groups + g) * 2 + 0] = meanf;
+    stats[((size_t)n * groups + g) * 2 + 1] = rstdf;
+  }
+  if (coef4) {
+    for (int cl = threadIdx.x; cl < cpg; cl += blockDim.x) {
+      const int c = g * cpg + cl;
+      const float ga = gamma[c], be = beta[c];
+      reinterpret_cast<float4*>(coef4)[(size_t)n * CP + c] = make_float4(rstdf * ga, be - meanf * rstdf * ga, meanf, rstdf);
+    }
   }
 }
 
@@ -262,7 +274,7 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
           act_fwd8<FastMath<T>::value>(v, sc, sh, act, v);
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] += v[j];
-          V8<T>::st(out + idx, v);
+          if (out) V8<T>::st(out + idx, v);
         }
       }
     if (POOL > 1 && by < Hp && bx < Wp) {
@@ -561,6 +573,120 @@ __global__ void k_fold_padded(T* __restrict__ buf, int C8, int H, int W, int p, 
   }
 }
 
+// The same padding adjoint for a gradient buffer whose non-frame pixels already hold dz = dA * act'(z) (written by the
+// input-gradient kernel's epilogue): EVERY frame pixel (within p + 1 of the border; `all`: every pixel) gets its halo
+// sources added, is turned into dz in place and contributes to this block's (sum dz, sum dz * yhat) partials
+// part[n][stride][CP][2] at slot first + blockIdx.x.  With zero padding there is nothing to fold and no frame.
+template <typename T>
+__global__ __launch_bounds__(256) void k_fold_padded_dz(T* __restrict__ buf, int C8, int H, int W, int p, int mode, int all,
+                                                        const T* __restrict__ y, const float* __restrict__ coef4, int act,
+                                                        float* __restrict__ part, int stride, int first) {
+  const int n = blockIdx.z, cb = blockIdx.y;
+  const int t = p + 1;
+  const int band = all ? H * W : 2 * t * W;
+  const int side = all ? 0 : (H - 2 * t) * 2 * t;
+  const int Hp = H + 2 * p, Wp = W + 2 * p, CP = C8 * 8;
+  float sc[8], sh[8], me[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (coef4) {
+      const float4 c4 = reinterpret_cast<const float4*>(coef4)[(size_t)n * CP + cb * 8 + j];
+      sc[j] = c4.x; sh[j] = c4.y; me[j] = c4.z; rs[j] = c4.w;
+    } else { sc[j] = 1.f; sh[j] = 0.f; me[j] = 0.f; rs[j] = 0.f; }
+  }
+  float s[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one pixel per thread (the launch covers band + side)
+  if (i < band + side) {
+    int yy, xx;
+    if (all) {
+      yy = i / W;
+      xx = i - yy * W;
+    } else if (i < band) {
+      int r = i / W;
+      xx = i - r * W;
+      yy = r < t ? r : H - 2 * t + r;
+    } else {
+      int k = i - band;
+      int r = k / (2 * t), c = k - r * 2 * t;
+      yy = t + r;
+      xx = c < t ? c : W - 2 * t + c;
+    }
+    int cy[6], cx[6];
+    const int ny = fold_candidates(yy, H, p, mode, cy), nx = fold_candidates(xx, W, p, mode, cx);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        float v[8];
+        V8<T>::ld(buf + cb8_index(n, cb, cy[a], cx[b], C8, Hp, Wp), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    float yv[8], gz[8];
+    V8<T>::ld(y + cb8_index(n, cb, yy, xx, C8, H, W), yv);
+    act_bwd8<FastMath<T>::value>(yv, sc, sh, act, gz);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dz = acc[j] * gz[j];
+      acc[j] = dz;
+      s[2 * j] = dz;
+      s[2 * j + 1] = dz * (yv[j] - me[j]) * rs[j];
+    }
+    V8<T>::st(buf + cb8_index(n, cb, yy + p, xx + p, C8, Hp, Wp), acc);
+  }
+  __shared__ float red[4][16];
+  int idx;
+  float r = wave_sum16(s, threadIdx.x & 63, idx);
+  if ((threadIdx.x & 3) == 0) red[threadIdx.x >> 6][idx] = r;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    part[(((size_t)n * stride + first + blockIdx.x) * CP + cb * 8 + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] = tot;
+  }
+}
+
+// GroupNorm backward, last phase, from dz (see mc_gn_bwd_apply_dz): dy = scale dz - rstd (m1 + yhat m2); coef4 == NULL
+// (activation-only layer): dy = dz.  Rows x columns flattened like k_gn_bwd_apply.
+template <typename T, int GK>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply_dz(mc_grad_src gs, const T* __restrict__ y, int C, int C8, int H, int W,
+                                                         int groups, const float* __restrict__ coef4,
+                                                         const float* __restrict__ m12, T* __restrict__ dy, int rows_pb, int rev) {
+  const int n = rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y;
+  float cA[8], cB[8], cC[8], me[8];
+  const int cpg = C / groups;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j;
+    cA[j] = (c < C) ? 1.f : 0.f; cB[j] = 0.f; cC[j] = 0.f; me[j] = 0.f;
+    if (coef4 && c < C) {
+      const float4 c4 = reinterpret_cast<const float4*>(coef4)[(size_t)n * C8 * 8 + c];
+      const int g = c / cpg;
+      const float m1 = m12[((size_t)n * groups + g) * 2], m2 = m12[((size_t)n * groups + g) * 2 + 1];
+      cA[j] = c4.x;                     // rstd * gamma
+      cB[j] = -c4.w * c4.w * m2;
+      cC[j] = -c4.w * m1;
+      me[j] = c4.z;
+    }
+  }
+  const int y0 = blockIdx.x * rows_pb, nrows = min(rows_pb, H - y0);
+  for (int i = threadIdx.x; i < nrows * W; i += blockDim.x) {
+    const int ry = i / W, xx = i - ry * W, yy = y0 + ry;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dz[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+    const size_t idx = cb8_index(n, cb, yy, xx, C8, H, W);
+    if (coef4) V8<T>::ld(y + idx, v);
+    grad_fetch_add<T, GK>(gs, n, cb, yy, xx, C8, dz);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 t = (f32x2){v[j], v[j + 1]} - (f32x2){me[j], me[j + 1]};
+      const f32x2 r = pk_fma((f32x2){cA[j], cA[j + 1]}, (f32x2){dz[j], dz[j + 1]},
+                             pk_fma((f32x2){cB[j], cB[j + 1]}, t, (f32x2){cC[j], cC[j + 1]}));
+      o[j] = r.x; o[j + 1] = r.y;
+    }
+    V8<T>::st(dy + idx, o);
+  }
+}
+
 // =================================================================================================
 // bicubic resampling with host-built tap tables
 // =================================================================================================
@@ -572,7 +698,10 @@ constexpr int FOH = 16, FOW = 64, FWH = 12, FWW = 36;
 template <typename T>
 __device__ __forceinline__ void bicubic_direct(const T* __restrict__ x, int n, int cb, int C8, int Hi, int Wi, int yo, int xo,
                                                const int* __restrict__ iy, const float* __restrict__ wy,
-                                               const int* __restrict__ ix, const float* __restrict__ wx, float (&acc)[8]) {
+                                               const int* __restrict__ ix, const float* __restrict__ wx, float (&acc)[8],
+                                               const float* __restrict__ coef4, int act) {
+  float sc[8], sh[8];
+  if (act >= 0) load_coef8(coef4, n, C8 * 8, cb, sc, sh);
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
@@ -583,6 +712,13 @@ __device__ __forceinline__ void bicubic_direct(const T* __restrict__ x, int n, i
     for (int b = 0; b < 4; ++b) {
       float v[8];
       V8<T>::ld(x + cb8_index(n, cb, ys, ix[xo * 4 + b], C8, Hi, Wi), v);
+      if (act >= 0) {
+        act_fwd8<FastMath<T>::value>(v, sc, sh, act, v);
+        if (sizeof(T) == 2) {                              // the staged window holds the activation in the storage type
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = bf2f(f2bf(v[j]));
+        }
+      }
       float w = wa * wx[xo * 4 + b];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
@@ -590,11 +726,31 @@ __device__ __forceinline__ void bicubic_direct(const T* __restrict__ x, int n, i
   }
 }
 
+// one CB8 vector held as raw registers (Q = 1: 8 bf16, Q = 2: 8 f32) -> act(scale * v + shift) in the storage type
+template <typename T> struct XformRaw;
+template <> struct XformRaw<bf16_t> {
+  static __device__ __forceinline__ void apply(uint4 (&r)[1], const float (&sc)[8], const float (&sh)[8], int act) {
+    r[0] = xform_bf16x8(r[0], sc, sh, act);
+  }
+};
+template <> struct XformRaw<float> {
+  static __device__ __forceinline__ void apply(uint4 (&r)[2], const float (&sc)[8], const float (&sh)[8], int act) {
+    float v[8] = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), __uint_as_float(r[0].w),
+                  __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w)};
+    act_fwd8<false>(v, sc, sh, act, v);
+    r[0] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    r[1] = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+  }
+};
+
+// coef4 / act: x is a raw conv output; the producer's GroupNorm affine + activation are applied while the window is staged
+// (act < 0: x is used as it is)
 template <typename T>
 __global__ __launch_bounds__(256) void k_bicubic_fwd(const T* __restrict__ x, int C8, int Hi, int Wi, int Ho, int Wo,
                                                      const int* __restrict__ iy, const float* __restrict__ wy,
                                                      const int* __restrict__ ix, const float* __restrict__ wx,
-                                                     T* __restrict__ out, int tiles_x) {
+                                                     T* __restrict__ out, int tiles_x, const float* __restrict__ coef4,
+                                                     int act) {
   __shared__ __attribute__((aligned(16))) T win[FWH * FWW * 8];
   __shared__ float4 tmp[2][FWH][FOW];
   const int n = blockIdx.z, cb = blockIdx.y;
@@ -610,6 +766,12 @@ __global__ __launch_bounds__(256) void k_bicubic_fwd(const T* __restrict__ x, in
       const T* p = x + cb8_index(n, cb, min(ylo + r, Hi - 1), min(xlo + c, Wi - 1), C8, Hi, Wi);
 #pragma unroll
       for (int q = 0; q < Q; ++q) rv[m][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p) + 16 * q);
+    }
+    if (act >= 0) {
+      float sc[8], sh[8];
+      load_coef8(coef4, n, C8 * 8, cb, sc, sh);
+#pragma unroll
+      for (int m = 0; m < VPT; ++m) XformRaw<T>::apply(rv[m], sc, sh, act);
     }
 #pragma unroll
     for (int m = 0; m < VPT; ++m) {
@@ -669,7 +831,7 @@ __global__ __launch_bounds__(256) void k_bicubic_fwd(const T* __restrict__ x, in
         acc[4] += wa * p1.x; acc[5] += wa * p1.y; acc[6] += wa * p1.z; acc[7] += wa * p1.w;
       }
     } else {
-      bicubic_direct<T>(x, n, cb, C8, Hi, Wi, yo, xo, iy, wy, ix, wx, acc);
+      bicubic_direct<T>(x, n, cb, C8, Hi, Wi, yo, xo, iy, wy, ix, wx, acc, coef4, act);
     }
     V8<T>::st(out + cb8_index(n, cb, yo, xo, C8, Ho, Wo), acc);
   }
@@ -1072,13 +1234,25 @@ int mc_gn_partials(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, in
   return MC_OK;
 }
 
+int mc_gn_finalize_coef(const float* part, int32_t n, int32_t tiles, int32_t c, int32_t groups, int32_t hw, float eps,
+                        const float* gamma, const float* beta, float* stats, float* coef4, void* stream) {
+  if (!part || n <= 0 || tiles <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || hw <= 0) return MC_EINVAL;
+  if (!stats && !coef4) return MC_EINVAL;
+  if (coef4 && (!gamma || !beta)) return MC_EINVAL;
+  int CP = ((c + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_gn_finalize, dim3(groups, n), dim3(64), 0, (hipStream_t)stream, part, tiles, c, CP, groups, hw,
+                     eps, stats, nullptr, gamma, beta, coef4);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
 int mc_gn_finalize(const float* part, int32_t n, int32_t tiles, int32_t c, int32_t groups, int32_t hw, float eps,
                    float* stats, float* chan_mean, void* stream) {
   if (!part || n <= 0 || tiles <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || hw <= 0) return MC_EINVAL;
   if (!stats && !chan_mean) return MC_EINVAL;
   int CP = ((c + 7) / 8) * 8;
   hipLaunchKernelGGL(k_gn_finalize, dim3(groups, n), dim3(64), 0, (hipStream_t)stream, part, tiles, c, CP, groups, hw,
-                     eps, stats, chan_mean);
+                     eps, stats, chan_mean, nullptr, nullptr, nullptr);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -1102,7 +1276,7 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
-  if (!y || !a_out || (pool > 1 && !pooled)) return MC_EINVAL;
+  if (!y || (!a_out && pool == 1) || (pool > 1 && !pooled)) return MC_EINVAL;
   if (pool != 1 && pool != 2 && pool != 4) return MC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int per = cdiv(h, pool) * cdiv(w, pool);
@@ -1227,6 +1401,59 @@ int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int3
   return MC_OK;
 }
 
+static void fold_shape(int hs, int ws, int pad, int& all, int& total) {
+  const int t = pad + 1;
+  all = (hs < 2 * t || ws < 2 * t) ? 1 : 0;
+  total = all ? hs * ws : 2 * t * ws + (hs - 2 * t) * 2 * t;
+}
+
+int32_t mc_fold_blocks(int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode) {
+  if (hs <= 0 || ws <= 0 || pad <= 0 || pad_mode == MC_PAD_ZEROS) return 0;
+  int all, total;
+  fold_shape(hs, ws, pad, all, total);
+  return cdiv(total, 256);
+}
+
+int mc_fold_padded_dz(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode, int32_t dtype,
+                      const void* y, const float* coef, int32_t act, float* partials, int32_t part_stride_blocks,
+                      int32_t part_first_block, void* stream) {
+  if (!buf || !y || !partials || n <= 0 || c <= 0 || hs <= 0 || ws <= 0 || pad < 0 || pad > 2) return MC_EINVAL;
+  if (act < MC_ACT_NONE || act > MC_ACT_ELU) return MC_EINVAL;
+  const int blocks = mc_fold_blocks(hs, ws, pad, pad_mode);
+  if (blocks == 0) return MC_OK;                              // zero padding: every interior pixel was final already
+  if (part_first_block < 0 || part_first_block + blocks > part_stride_blocks) return MC_EINVAL;
+  int all, total;
+  fold_shape(hs, ws, pad, all, total);
+  const int C8 = (c + 7) / 8;
+  dim3 g(blocks, C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded_dz<float>, g, dim3(256), 0, s, (float*)buf, C8, hs, ws, pad, pad_mode, all, (const float*)y, coef, act, partials, part_stride_blocks, part_first_block);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_fold_padded_dz<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all, (const bf16_t*)y, coef, act, partials, part_stride_blocks, part_first_block);
+  else return MC_EUNSUPPORTED;
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_bwd_apply_dz(const mc_grad_src* dz, const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                       const float* coef, const float* m12, int32_t dtype, void* dy, void* stream) {
+  if (!dz || !dy || n <= 0 || c <= 0 || h <= 0 || w <= 0) return MC_EINVAL;
+  if (coef && (!y || !m12 || groups <= 0 || c % groups != 0)) return MC_EINVAL;
+  int rc = check_gsrc(dz);
+  if (rc) return rc;
+  if ((dz->kind != MC_GSRC_PADFOLD && dz->kind != MC_GSRC_PLAIN) || dz->c8_total != 0 || dz->hs != h || dz->ws != w) return MC_EUNSUPPORTED;
+  const int rows = gn_apply_rows(h, w), C8 = (c + 7) / 8;
+  dim3 g(cdiv(h, rows), C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  const int gr = groups > 0 ? groups : 1;
+#define APZ(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply_dz<T, GK>), g, dim3(256), 0, s, *dz, (const T*)y, c, C8, h, w, gr, coef, m12, (T*)dy, rows, mc_g_reverse)
+  if (dtype == MC_F32) { if (dz->kind == MC_GSRC_PADFOLD) APZ(float, MC_GSRC_PADFOLD); else APZ(float, MC_GSRC_PLAIN); }
+  else if (dtype == MC_BF16) { if (dz->kind == MC_GSRC_PADFOLD) APZ(bf16_t, MC_GSRC_PADFOLD); else APZ(bf16_t, MC_GSRC_PLAIN); }
+  else return MC_EUNSUPPORTED;
+#undef APZ
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
 int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
                               const float* partials, int32_t blocks, const float* gamma, const float* beta, int32_t act,
                               int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, float* dgamma, float* dbeta,
@@ -1302,20 +1529,28 @@ int mc_gsrc_sum(const mc_grad_src* g0, const mc_grad_src* g1, int32_t n, int32_t
   return MC_OK;
 }
 
-int mc_bicubic_fwd(const void* x, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
-                   const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x, const float* wgt_x, int32_t dtype,
-                   void* out, void* stream) {
+int mc_bicubic_fwd_act(const void* x, const float* coef, int32_t act, int32_t n, int32_t c, int32_t hi, int32_t wi,
+                       int32_t ho, int32_t wo, const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x,
+                       const float* wgt_x, int32_t dtype, void* out, void* stream) {
   if (!x || !out || !idx_y || !wgt_y || !idx_x || !wgt_x || n <= 0 || c <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0)
     return MC_EINVAL;
+  if (act < MC_ACT_NONE || act > MC_ACT_ELU) return MC_EINVAL;
+  const int a = (coef == nullptr && act == MC_ACT_NONE) ? -1 : act;      // -1: x is used as it is
   int C8 = (c + 7) / 8;
   int tiles_x = cdiv(wo, FOW), tiles_y = cdiv(ho, FOH);
   dim3 g(tiles_x * tiles_y, C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_fwd<float>, g, dim3(256), 0, s, (const float*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (float*)out, tiles_x);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_fwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (bf16_t*)out, tiles_x);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_fwd<float>, g, dim3(256), 0, s, (const float*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (float*)out, tiles_x, coef, a);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_fwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (bf16_t*)out, tiles_x, coef, a);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
+}
+
+int mc_bicubic_fwd(const void* x, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                   const int32_t* idx_y, const float* wgt_y, const int32_t* idx_x, const float* wgt_x, int32_t dtype,
+                   void* out, void* stream) {
+  return mc_bicubic_fwd_act(x, nullptr, MC_ACT_NONE, n, c, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, dtype, out, stream);
 }
 
 int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,

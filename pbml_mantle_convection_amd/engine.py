@@ -340,6 +340,12 @@ class _T:            # runtime tensor
     buf: Optional[torch.Tensor] = None
     requires_grad: bool = True
     gsrcs: list = field(default_factory=list)   # gradient sources registered during backward
+    # "normalise on load": the activated tensor is never materialised; consumers read the producer's raw conv output
+    # `raw` and apply act(scale * y + shift) from `coef` ([N, CP, 4] table, None = activation only) while staging
+    fused: bool = False
+    raw: Optional[torch.Tensor] = None
+    coef: Optional[torch.Tensor] = None
+    act: int = 0
 
 
 class Engine:
@@ -365,6 +371,10 @@ class Engine:
         self.zigzag = int(os.environ.get("MANTLE_ZIGZAG", "0"))
         self._dirn = 0
         self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "1"))   # A/B on MI355X: 1 is 0.25 ms/step faster than 0, 2 is no gain
+        # bit 0: GroupNorm + activation applied by the consumers on load (conv, filter gradient, bicubic) instead of a
+        # stand-alone pass that materialises the activated tensor; bit 1: the GroupNorm-backward reduction fused into the
+        # epilogue of the input-gradient launch (single-consumer tensors).  0 = the round-1 unfused chain (A/B, tests).
+        self.fuse = int(os.environ.get("MANTLE_FUSE", "3"))
 
     # -------------------------------------------------------------- planning
     def configure(self, N: int, H: int, W: int, device):
@@ -388,6 +398,13 @@ class Engine:
             return torch.empty((N, (c + 7) // 8, h, w, 8), dtype=self.t_dtype, device=device)
 
         T[0].buf = cb8(T[0].C, T[0].H, T[0].W)
+        # consumers of every tensor (decides which activated tensors need not be materialised)
+        cons: Dict[int, list] = {tid: [] for tid in g.channels}
+        for node in g.nodes:
+            for i in (node.srcs if node.kind in ("conv", "cat") else [node.src]):
+                cons[i].append(node)
+        self.cons = cons
+        self.prod = {}                       # tensor id -> plan entry of the conv that produced it (full-resolution output)
         for node in g.nodes:
             if node.kind == "up":
                 s = T[node.src]
@@ -454,12 +471,20 @@ class Engine:
                      part=torch.empty((N, tiles, coutp, 2), **f32),
                      bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
                      need_dgrad=need_dgrad)
-            if node.post != L.POST_NONE:
+            fusable = all(c.kind == "up" or (c.kind == "conv" and not c.learned) for c in cons[node.out])
+            o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1))
+            if o.fused:
+                o.raw, o.act = e["Y"], L.ACTS[g.act]
+            elif node.post != L.POST_NONE:
                 o.buf = cb8(node.c_out, ho, wo)
             else:
                 o.buf = e["Y"]
+            self.prod[node.out] = e
             if node.post == L.POST_GN_ACT:
                 e["stats"] = torch.empty((N, node.groups, 2), **f32)
+                e["coef"] = torch.zeros((N, coutp, 4), **f32)       # (scale, shift, mean, rstd); padded channels stay 0
+                if o.fused:
+                    o.coef = e["coef"]
                 blocks = L.call("mc_gn_bwd_blocks", ho, wo)
                 e["gblocks"] = blocks
                 e["gpart"] = torch.empty((N, blocks, coutp, 2), **f32)
@@ -473,6 +498,18 @@ class Engine:
                                          device=device)
                 hp, wp = h + 2 * node.pad, w + 2 * node.pad
                 e["dxp"] = [cb8(s.C, hp, wp) for s in srcs]
+                # GroupNorm-backward reduction fused into this launch's epilogue: the source is the full-resolution output
+                # of a conv + (GN) + act layer and this conv is its only consumer
+                pe = self.prod.get(node.srcs[0])
+                if ((self.fuse & 2) and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
+                        and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1):
+                    dtiles = L.call("mc_conv_tiles", C.byref(dd))
+                    fblocks = L.call("mc_fold_blocks", h, w, node.pad, mode)
+                    e["epi"] = pe
+                    pe["dz_tiles"], pe["dz_blocks"] = dtiles, dtiles + fblocks
+                    pe["dz_part"] = torch.empty((N, dtiles + fblocks, pe["coutp"], 2), **f32)
+                    if "m12" not in pe and pe["node"].post == L.POST_GN_ACT:
+                        pe["m12"] = torch.empty((N, pe["node"].groups, 2), **f32)
             max_dy = max(max_dy, N * coutp * ho * wo)
             # per-layer filter-gradient partial slabs: all layers are combined by ONE batched launch at the end of backward
             e["wpart"] = torch.empty(L.call("mc_wgrad_partial_bytes", C.byref(d)), dtype=torch.uint8, device=device)
@@ -654,8 +691,12 @@ class Engine:
             if node.kind == "up":
                 s, o = T[node.src], T[node.out]
                 (iy, wy, *_), (ix, wx, *_) = e["tabs"]
-                L.call("mc_bicubic_fwd", L.ptr(s.buf), N, s.C, s.H, s.W, o.H, o.W, L.ptr(iy), L.ptr(wy), L.ptr(ix),
-                       L.ptr(wx), self.mc_dtype, L.ptr(o.buf), st)
+                if s.fused:      # the producer's GroupNorm + activation are applied while the input window is staged
+                    L.call("mc_bicubic_fwd_act", L.ptr(s.raw), L.ptr(s.coef), s.act, N, s.C, s.H, s.W, o.H, o.W, L.ptr(iy),
+                           L.ptr(wy), L.ptr(ix), L.ptr(wx), self.mc_dtype, L.ptr(o.buf), st)
+                else:
+                    L.call("mc_bicubic_fwd", L.ptr(s.buf), N, s.C, s.H, s.W, o.H, o.W, L.ptr(iy), L.ptr(wy), L.ptr(ix),
+                           L.ptr(wx), self.mc_dtype, L.ptr(o.buf), st)
                 continue
             d = e["desc"]
             if not node.learned:
@@ -665,20 +706,28 @@ class Engine:
             o = T[node.out]
             final = node.post == L.POST_NONE
             need_part = node.post == L.POST_GN_ACT or (final and g.subtract_mean)
+            gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
+            beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
             if node.learned:
                 self._learned_forward(e, srcs[0], params, need_part, st)
             else:
                 self._direction("conv")
                 self._probe_begin()
-                L.call("mc_conv2d", C.byref(d), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf) if len(srcs) > 1 else None,
-                       L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None, L.ptr(e["part"]) if need_part else None, st)
+                x0, x1, pro = self._sources(srcs)
+                L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None,
+                       L.ptr(e["part"]) if need_part else None, None, st)
                 self._probe_end(d, "fwd " + node.name)
             if node.post == L.POST_GN_ACT:
-                L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
-                       L.ptr(e["stats"]), None, st)
-            if not final:
-                gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
-                beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
+                # (mean, rstd) per (sample, group) + the (scale, shift, mean, rstd) table consumers normalise on load with
+                L.call("mc_gn_finalize_coef", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
+                       L.ptr(gamma), L.ptr(beta), L.ptr(e["stats"]), L.ptr(e.get("coef")), st)
+            if o.fused:
+                if node.pool > 1:      # only the pooled tensor is materialised
+                    self._direction("gn_rev")
+                    L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
+                           L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype, None,
+                           L.ptr(T[node.pooled].buf), st)
+            elif not final:
                 pooled = T[node.pooled].buf if node.pool > 1 else None
                 self._direction("gn_rev")
                 L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
@@ -694,6 +743,19 @@ class Engine:
         L.call("mc_unpack_nchw", L.ptr(fo.buf), N, fo.C, fo.H, fo.W, g.crop_w, L.ptr(self.chan_mean), out_dt,
                L.ptr(out), st)
         return out
+
+    @staticmethod
+    def _sources(srcs):
+        """(x0, x1, prologue) of a conv's one or two sources: a fused tensor is read as the producer's raw conv output with
+        its (scale, shift) table and activation; anything else as it is."""
+        ptrs = [L.ptr(t.raw if t.fused else t.buf) for t in srcs] + [None]
+        if not any(t.fused for t in srcs):
+            return ptrs[0], ptrs[1], None
+        t1 = srcs[1] if len(srcs) > 1 else None
+        pro = L.ConvPrologue(L.ptr(srcs[0].coef) if srcs[0].fused else None,
+                             L.ptr(t1.coef) if (t1 is not None and t1.fused) else None,
+                             srcs[0].act if srcs[0].fused else 0, t1.act if (t1 is not None and t1.fused) else 0)
+        return ptrs[0], ptrs[1], C.byref(pro)
 
     @staticmethod
     def _param(params, name):
@@ -777,7 +839,20 @@ class Engine:
             dY = self.dYs[k & 1]
             if wg_done[k & 1] is not None:
                 main.wait_event(wg_done[k & 1])          # the side stream has finished reading this dY buffer
-            if node.post != L.POST_NONE:
+            if node.post != L.POST_NONE and "dz" in e:
+                # dz = dA * act'(z) and its partial sums were produced by the consumer's input-gradient launch
+                assert not o.gsrcs, f"{node.name}: fused dz and separate gradient sources"
+                if node.post == L.POST_GN_ACT:
+                    gamma = self._param(params, node.gn_name + "weight")
+                    L.call("mc_gn_act_bwd_finalize", L.ptr(e["dz_part"]), N, e["dz_blocks"], node.c_out, node.groups,
+                           o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
+                           L.ptr(grads[node.gn_name + "bias"]), st)
+                self._direction("gn_fwd")
+                L.call("mc_gn_bwd_apply_dz", C.byref(e["dz"]), L.ptr(e["Y"]), N, node.c_out, o.H, o.W, max(node.groups, 1),
+                       L.ptr(e["coef"]) if node.post == L.POST_GN_ACT else None, L.ptr(e.get("m12")), self.mc_dtype,
+                       L.ptr(dY), st)
+                del e["dz"]
+            elif node.post != L.POST_NONE:
                 gs = list(o.gsrcs)
                 if node.pool > 1:
                     p = T[node.pooled]
@@ -815,8 +890,7 @@ class Engine:
                 self._learned_backward(e, srcs[0], dY, params, grads, st)
                 k += 1
                 continue
-            x0 = L.ptr(srcs[0].buf)
-            x1 = L.ptr(srcs[1].buf) if len(srcs) > 1 else None
+            x0, x1, pro = self._sources(srcs)
             side = self.side if (self.overlap_wgrad == 1 or (self.overlap_wgrad == 2 and o.H * o.W <= 128 * 128)) else main
             wg_done[k & 1] = None
             if side is not main:
@@ -826,7 +900,7 @@ class Engine:
             self._direction("conv")                    # the filter and the input gradient both start on the dY written last
             with torch.cuda.stream(side):
                 ss = L.stream()
-                L.call("mc_conv2d_wgrad", C.byref(d), x0, x1, L.ptr(dY), L.ptr(e["wpart"]), ss)
+                L.call("mc_conv2d_wgrad_fused", C.byref(d), x0, x1, pro, L.ptr(dY), L.ptr(e["wpart"]), ss)
                 if self.wfin_per_layer and side is not main:
                     # combine this layer's partial slabs right away on the side stream (hidden under the main chain)
                     L.call("mc_conv2d_wgrad_finalize", C.byref(d), L.ptr(e["wpart"]), L.ptr(grads[node.name + "weight"]),
@@ -841,6 +915,21 @@ class Engine:
             if e["need_dgrad"]:
                 dxp = e["dxp"]
                 self._direction("keep")
+                pe = e.get("epi")
+                if pe is not None:
+                    # the source's GroupNorm-backward reduction rides in this launch: dz and its partial sums instead of dA
+                    pn, s0 = pe["node"], srcs[0]
+                    coef = L.ptr(pe["coef"]) if pn.post == L.POST_GN_ACT else None
+                    epi = L.ConvEpilogue(L.ptr(pe["Y"]), coef, act, node.pad, self.mode, s0.H, s0.W, L.ptr(pe["dz_part"]),
+                                         pe["dz_blocks"])
+                    self._probe_begin()
+                    L.call("mc_conv2d_fused", C.byref(e["ddesc"]), L.ptr(dY), None, None, L.ptr(e["dbank"]), None,
+                           L.ptr(dxp[0]), None, None, C.byref(epi), st)
+                    self._probe_end(e["ddesc"], "dgrad " + node.name)
+                    L.call("mc_fold_padded_dz", L.ptr(dxp[0]), N, s0.C, s0.H, s0.W, node.pad, self.mode, self.mc_dtype,
+                           L.ptr(pe["Y"]), coef, act, L.ptr(pe["dz_part"]), pe["dz_blocks"], pe["dz_tiles"], st)
+                    pe["dz"] = L.GradSrc(L.ptr(dxp[0]), L.GSRC_PADFOLD, node.pad, self.mode, 1, s0.H, s0.W)
+                    continue
                 self._probe_begin()
                 L.call("mc_conv2d", C.byref(e["ddesc"]), L.ptr(dY), None, L.ptr(e["dbank"]), None, L.ptr(dxp[0]),
                        L.ptr(dxp[1]) if len(dxp) > 1 else None, None, st)
