@@ -78,7 +78,7 @@ def _odd_poly(t: Tensor, coef) -> Tensor:
 
 
 def gelu_bf16_mode(t: Tensor) -> Tensor:
-    return t * _odd_poly(t, GELU_CDF_POLY).clamp(0.0, 1.0)
+    return t * _odd_poly(t, GELU_CDF_POLY)      # (the device does not clamp Phi to [0, 1]: it stays within the fit error)
 
 
 def gelu_grad_bf16_mode(t: Tensor) -> Tensor:

@@ -8,10 +8,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmantle_hip.so")
-SOURCES = ["elementwise.hip", "conv_api.hip", "conv_f32.hip", "conv_bf16.hip", "loss.hip", "optim.hip"]
-HEADERS = ["common.h", "conv_common.h", os.path.join("..", "..", "include", "mantle_hip.h")]
+SOURCES = ["elementwise.hip", "conv_api.hip", "conv_f32.hip", "conv_bf16.hip", "conv_rr_bf16.hip", "loss.hip", "optim.hip"]
+HEADERS = ["common.h", "conv_common.h", "conv_rr.h", os.path.join("..", "..", "include", "mantle_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
+
+
+# conv_rr_bf16.hip: the loader waves' activation transform must stay single-issue f32 FMAs (see rr_gelu_bf16x8)
+EXTRA_FLAGS = {"conv_rr_bf16.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -33,7 +37,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -1,5 +1,5 @@
 // C-ABI dispatch for the convolution entry points + filter-bank packing + filter-gradient combine.
-#include "conv_common.h"
+#include "conv_rr.h"
 
 int mc_conv2d_f32(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
                   void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s);
@@ -15,20 +15,40 @@ int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void*
                   hipStream_t s);
 const char* mc_bf16_kernel_name(const ConvGeom& g);
 void mc_bf16_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles);
+// row-reuse bf16 path for single-output-tile layers (conv_rr_bf16.hip)
+bool mc_rr_applies(const ConvGeom& g);
+size_t mc_rr_bank_bytes(const ConvGeom& g, int dgrad);
+int mc_rr_pack(const ConvGeom& g, const float* w_unique, int dgrad, void* packed, hipStream_t s);
+int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
+                 float* part, const ConvFuse& fz, int fuse, hipStream_t s);
+const char* mc_rr_kernel_name(const ConvGeom& g, int fuse);
 
 namespace {
+
+// forward / input-gradient kernel family of a descriptor: the row-reuse kernel takes the layers with one 16-channel
+// output tile per work-group (an odd number of output tiles), the wide-tile kernel the rest
+bool rr_desc(const mc_conv_desc* d) {
+  ConvGeom t;
+  t.dtype = d->dtype; t.Cout = d->c_out;
+  return d->dtype == MC_BF16 && mc_rr_applies(t);
+}
 
 int geom_for(const mc_conv_desc* d, ConvGeom& g) {
   if (!d) return MC_EINVAL;
   int th = 16, tw = 16;
   if (d->dtype == MC_BF16) {
-    int rc = mc_bf16_tile(d, &th, &tw);
-    if (rc) return rc;
+    if (rr_desc(d)) { th = RR_R; tw = RR_TW; }
+    else {
+      int rc = mc_bf16_tile(d, &th, &tw);
+      if (rc) return rc;
+    }
   } else if (d->dtype != MC_F32) {
     return MC_EUNSUPPORTED;
   }
   return conv_geom(d, th, tw, g);
 }
+// partial-sum slots per sample the forward / input-gradient kernel writes (one per tile; per (tile, strip) for row reuse)
+int stat_slots(const mc_conv_desc* d, const ConvGeom& g) { return rr_desc(d) ? g.tiles * RR_STRIPS : g.tiles; }
 
 // f32 bank: [cbin][tap][ci8][CoutP]
 __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, float* __restrict__ bank, size_t total) {
@@ -39,7 +59,7 @@ __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, 
 // ---- batched packing: the job table travels by value in the kernel arguments (<= PK_MAX jobs per launch)
 struct PkJob {
   int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP;
-  int dgrad, steps, ntiles, bf16, first_block;
+  int dgrad, steps, ntiles, bf16, rr, first_block;
   unsigned total;
   const float* w;
   void* out;
@@ -54,7 +74,8 @@ __global__ void k_pack_batched(PkTable t) {
   const PkJob& job = t.j[ji];
   const int nblk = (ji + 1 < t.n ? t.j[ji + 1].first_block : (int)gridDim.x) - job.first_block;
   for (size_t i = (size_t)(blockIdx.x - job.first_block) * blockDim.x + threadIdx.x; i < job.total; i += (size_t)nblk * blockDim.x) {
-    if (job.bf16) reinterpret_cast<bf16_t*>(job.out)[i] = f2bf(pack_value_bf16(job, job.w, i, job.dgrad, job.steps, job.ntiles));
+    if (job.rr) reinterpret_cast<bf16_t*>(job.out)[i] = f2bf(rr_pack_value(job, job.w, i, job.dgrad, job.ntiles));
+    else if (job.bf16) reinterpret_cast<bf16_t*>(job.out)[i] = f2bf(pack_value_bf16(job, job.w, i, job.dgrad, job.steps, job.ntiles));
     else reinterpret_cast<float*>(job.out)[i] = pack_value_f32(job, job.w, i, job.dgrad);
   }
 }
@@ -153,9 +174,18 @@ int wf_fill(const mc_conv_desc* d, const void* partials, float* dw, float* db, W
 
 }  // namespace
 
+// The input-gradient bank of a layer is consumed by the kernel family of the INPUT-GRADIENT convolution (whose output
+// channels are this layer's input channels), the forward bank by this layer's own family.
+static bool bank_is_rr(const ConvGeom& g, int dgrad) {
+  if (g.dtype != MC_BF16) return false;
+  ConvGeom t;
+  t.dtype = MC_BF16; t.Cout = dgrad ? g.Cin : g.Cout;
+  return mc_rr_applies(t);
+}
+
 extern "C" {
 
-int mc_version(void) { return 100; }
+int mc_version(void) { return 200; }
 
 const char* mc_strerror(int code) {
   switch (code) {
@@ -170,6 +200,7 @@ const char* mc_strerror(int code) {
 size_t mc_packed_weight_bytes(const mc_conv_desc* d, int32_t dgrad) {
   ConvGeom g;
   if (geom_for(d, g)) return 0;
+  if (bank_is_rr(g, dgrad)) return mc_rr_bank_bytes(g, dgrad);
   if (g.dtype == MC_BF16) return mc_bf16_bank_bytes(g, dgrad);
   int cbin = dgrad ? g.CBout : g.CBin, cop = dgrad ? g.CinP : g.CoutP;
   return (size_t)cbin * g.K * g.K * 8 * cop * sizeof(float);
@@ -180,6 +211,7 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!w_unique || !packed) return MC_EINVAL;
+  if (bank_is_rr(g, dgrad)) return mc_rr_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   if (g.dtype == MC_BF16) return mc_bf16_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   size_t total = mc_packed_weight_bytes(d, dgrad) / sizeof(float);
   int blocks = (int)((total + 255) / 256);
@@ -192,6 +224,7 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
 const char* mc_conv_kernel_name(const mc_conv_desc* d) {
   ConvGeom g;
   if (geom_for(d, g)) return "unsupported";
+  if (rr_desc(d)) return mc_rr_kernel_name(g, 0);
   if (g.dtype == MC_BF16) return mc_bf16_kernel_name(g);
   return g.K == 5 ? "k_conv_direct_f32<5>" : "k_conv_direct_f32<3>";
 }
@@ -199,7 +232,7 @@ const char* mc_conv_kernel_name(const mc_conv_desc* d) {
 int32_t mc_conv_tiles(const mc_conv_desc* d) {
   ConvGeom g;
   if (geom_for(d, g)) return -1;
-  return g.tiles;
+  return stat_slots(d, g);
 }
 
 static bool act_ok(int a) { return a >= MC_ACT_NONE && a <= MC_ACT_ELU; }
@@ -232,10 +265,11 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
     if (g.Ho != epi->hs + 2 * epi->pad || g.Wo != epi->ws + 2 * epi->pad) return MC_EINVAL;
     fz.ey = epi->y; fz.ecoef = epi->coef; fz.epart = epi->partials; fz.eact = epi->act; fz.epad = epi->pad;
     fz.ezero = epi->pad_mode == MC_PAD_ZEROS || epi->pad == 0; fz.ehs = epi->hs; fz.ews = epi->ws;
-    if (epi->part_stride < g.tiles) return MC_EINVAL;
+    if (epi->part_stride < stat_slots(d, g)) return MC_EINVAL;
     fz.estride = epi->part_stride;
     fuse = 2;
   }
+  if (rr_desc(d)) return mc_conv2d_rr(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   if (g.dtype == MC_BF16) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   return mc_conv2d_f32(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
 }
@@ -309,8 +343,13 @@ int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_uni
       PkJob& j = t.j[k];
       j.K = g.K; j.Cout = g.Cout; j.CBin = g.CBin; j.CB0 = g.CB0; j.Cin0 = g.Cin0; j.Cin1 = g.Cin1; j.Cin = g.Cin; j.U = g.U;
       j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = g.dtype == MC_BF16;
+      j.rr = bank_is_rr(g, j.dgrad);
       size_t total;
-      if (j.bf16) {
+      if (j.rr) {
+        j.steps = 0;
+        j.ntiles = ((j.dgrad ? g.CinP : g.Cout) + 15) / 16;
+        total = mc_rr_bank_bytes(g, j.dgrad) / 2;
+      } else if (j.bf16) {
         int chunks;
         mc_bf16_bank_dims(g, j.dgrad, chunks, j.steps, j.ntiles);
         total = (size_t)chunks * j.steps * j.ntiles * 64 * 8;

@@ -1,0 +1,544 @@
+// bf16 convolution for layers with one 16-channel output tile per work-group (C_out <= 16, or 48 = 3 groups): the
+// level-0 / level-1 layers of the U-Net, where two thirds of the FLOPs are and where the step is HBM-bound.
+//
+// "Row reuse": the implicit GEMM keeps v_mfma_f32_16x16x32_bf16 (A = filter fragment: M = 16 output channels; B = input
+// fragment: N = 16 pixels of a row; D: lane = pixel, 4 registers = 4 consecutive output channels), but the K = 32 slots of a
+// fragment are four (kx, channel block) pairs OF ONE INPUT ROW (pair order p = 2 kx + cb, 2K pairs per row, the pairs of two
+// consecutive rows packed into 2K/2 fragment "types").  One input fragment then feeds the K output rows it contributes to
+// (output row r = input row - ky) — K MFMAs per ds_read_b128 instead of one — and the filter fragments, 26 (k = 5) or
+// 10 (k = 3) per 16-channel input chunk, are loop invariants held in registers.  LDS reads per MFMA drop from 1.1 to 0.19
+// and the per-fragment address arithmetic disappears (every read is base + immediate): the old kernel was bound by
+// exactly those (LDS 39 %, VALU issue 45 %, MFMA 35 % busy, none saturated).
+//
+// Work-group = 8 waves, specialised:
+//   waves 0-3  MFMA: each owns a strip of 16 output rows x 16 columns of the 16 x 64 tile (16 accumulators), runs the
+//              K loop on the LDS tile of the current stage and the epilogue (bias, GroupNorm partial sums, store);
+//   waves 4-7  loaders: stage the (16+k-1) x (64+k-1) x 16-channel input window of the NEXT stage: raw buffer loads two
+//              stages ahead into registers, then — "normalise on load" — the producer's GroupNorm affine + activation on
+//              the vector ALU (it co-issues with the other waves' MFMAs), then ds_write into the other LDS buffer.
+// One s_barrier per stage.  A stage = one 16-channel input chunk of one (image, tile) work item; work-groups are persistent.
+// The input-gradient form (FUSE == 2) also stages the producer's raw output tile so that the epilogue can turn dA into
+// dz = dA act'(z) and emit GroupNorm-backward partial sums (see ConvFuse / mc_conv_epilogue).
+#include "conv_rr.h"
+#include <type_traits>
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// timing-only diagnostic build (tools/build_variant.sh stamps -DMC_RR_STAMPS): per-phase cycle totals of one work-group
+#ifdef MC_RR_STAMPS
+#define RR_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long now_ = clock64(); st_acc[k] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RR_STAMP(k) do {} while (0)
+#endif
+
+namespace {
+
+__device__ __forceinline__ int rr_xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+__global__ void k_pack_rr(ConvGeom g, const float* __restrict__ wu, int dgrad, bf16_t* __restrict__ bank, int ntiles, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    bank[i] = f2bf(rr_pack_value(g, wu, i, dgrad, ntiles));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS map (16-byte slots):  inbuf [2][2][PLANE] | wbuf [NW][NFRAG][64] | (FUSE == 2) ybuf [2][YSLOTS], ecl [16]
+//   NW = 2 for FUSE != 2 (layers with several input chunks: the loaders deliver the next stage's filter fragments with
+//   its window; one chunk: staged once), NW = 1 for FUSE == 2 (one chunk: staged once; several chunks — a rare shape —:
+//   the MFMA waves fetch their fragments from global memory per stage).
+// GELU: every fused activation is GELU (inline polynomial); otherwise the generic activation switch is compiled in.
+template <int K, int FUSE, bool OUT_F32, bool GELU>
+__global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
+                                                         const bf16_t* __restrict__ bank, const float* __restrict__ bias,
+                                                         bf16_t* __restrict__ y0, bf16_t* __restrict__ y1,
+                                                         float* __restrict__ part, ConvFuse fz) {
+  using S = RR<K>;
+  constexpr int TIH = S::TIH, TIW = S::TIW, PLANE = S::PLANE, NFRAG = S::NFRAG, NTY = S::NTYPES;
+  constexpr int PER = (TIH * TIW + 255) / 256;            // staging slots per loader thread and plane
+  constexpr int YSLOTS = RR_R * RR_TW, YPER = YSLOTS / 256;
+  constexpr int NW = FUSE == 2 ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* const inbuf = reinterpret_cast<uint4*>(smem_raw);
+  uint4* const wbuf = inbuf + 2 * 2 * PLANE;
+  uint4* const ybuf = wbuf + NW * NFRAG * 64;
+  float4* const ecl = reinterpret_cast<float4*>(ybuf + 2 * YSLOTS);
+
+  const int grp = blockIdx.y;                                                    // 16-channel output tile of this block
+  const int ntiles_total = gridDim.y;
+  const int bid = rr_xcd_remap(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunks = (g.CBin + 1) / 2;
+  const int items = g.N * g.tiles;
+  const int my_items = (items - bid + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_items * chunks;
+  if (total <= 0) return;                                   // (uniform: every wave of the work-group leaves)
+  const bool w_global = FUSE == 2 && chunks > 1;           // filter fragments straight from global memory (rare shape)
+
+  auto stage_coords = [&](int t, int& n, int& ty0, int& tx0, int& ck, int& tile) {
+    const int jitem = t / chunks;
+    ck = t - jitem * chunks;
+    const int wi = bid + jitem * (int)gridDim.x;
+    n = wi / g.tiles;
+    tile = wi - n * g.tiles;
+    ty0 = (tile / g.tiles_x) * RR_R;
+    tx0 = (tile % g.tiles_x) * RR_TW;
+  };
+  if (wave >= RR_STRIPS) {
+    // ================================================= loader waves =================================================
+    const int tl = threadIdx.x - 64 * RR_STRIPS;          // 0 .. 255
+    int s_rc[PER];
+    unsigned s_off[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      int i = tl + it * 256;
+      const bool live = i < TIH * TIW;
+      if (!live) i = TIH * TIW - 1;
+      const int r = i / TIW, c = i - r * TIW;
+      s_rc[it] = (live ? 0 : (1 << 31)) | (r << 15) | c;
+      s_off[it] = (unsigned)(r * g.W + c) * 16u;
+    }
+    v4u rin[2][2][PER];                                    // [register set][plane][slot]
+    unsigned okm[2] = {0xffffffffu, 0xffffffffu};
+    v4u yv[2][2][YPER];                                    // FUSE == 2: the producer's raw output at the tile's pixels
+    f32x4 ecv[2];                                          // FUSE == 2: (scale, shift, mean, rstd) of channel tl (tl < 16)
+    constexpr int WPER = (NFRAG * 64 + 255) / 256;         // filter-fragment slots per loader thread
+    v4u wv[2][WPER];                                       // the stage's filter fragments (staged through LDS for the MFMA waves)
+    const bool w_every = !w_global && chunks > 1;          // several chunks: a fresh set per stage; one chunk: stage 0 only
+
+    auto issue = [&](int t, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
+      int n, ty0, tx0, ck, tile;
+      stage_coords(t, n, ty0, tx0, ck, tile);
+      const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
+      const unsigned org16 = (unsigned)((ty0 - g.pad) * g.W + (tx0 - g.pad)) * 16u;
+      okm[SET] = 0xffffffffu;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int gcb = ck * 2 + cb;
+        const int gcc = min(gcb, g.CBin - 1);
+        const bool second = gcc >= g.CB0;
+        const int scb = second ? gcc - g.CB0 : gcc;
+        const int sC8 = second ? g.CB1 : g.CB0;
+        const size_t plane_bytes = (size_t)g.H * g.W * 16;
+        const char* pbase = reinterpret_cast<const char*>(second ? x1 : x0) + ((size_t)n * sC8 + scb) * plane_bytes;
+        // one descriptor per (image, channel-block plane): out-of-range offsets return zeros = zero padding / missing block
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, gcb < g.CBin ? (int)plane_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+          unsigned off;
+          if (interior) {
+            off = org16 + s_off[it];
+          } else {
+            const int r = (s_rc[it] >> 15) & 0x7fff, c = s_rc[it] & 0x7fff;
+            bool oky, okx;
+            const int sy = pad_map_sel(ty0 + r - g.pad, g.H, g.pad_mode, oky);
+            const int sx = pad_map_sel(tx0 + c - g.pad, g.W, g.pad_mode, okx);
+            off = (oky && okx) ? (unsigned)(sy * g.W + sx) * 16u : 0xFFFFFFF0u;
+            if (FUSE == 1 && cb == 0 && !(oky && okx)) okm[SET] &= ~(1u << it);
+          }
+          rin[SET][cb][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        }
+      }
+      if (!w_global && (w_every || t == 0)) {
+        const v4u* wsrc = reinterpret_cast<const v4u*>(bank) + (size_t)(ck * ntiles_total + grp) * NFRAG * 64;
+#pragma unroll
+        for (int it = 0; it < WPER; ++it) wv[SET][it] = wsrc[min(tl + it * 256, NFRAG * 64 - 1)];
+      }
+      if constexpr (FUSE == 2) {
+        if (ck == chunks - 1) {
+          // y at the interior coordinates of the tile's (padded-domain) output pixels; clamped: the epilogue only uses
+          // the pixels it finalises
+          const bf16_t* ey = reinterpret_cast<const bf16_t*>(fz.ey);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int cbc = min(grp * 2 + cb, g.CBout - 1);
+#pragma unroll
+            for (int it = 0; it < YPER; ++it) {
+              const int i = tl + it * 256, r = i / RR_TW, c = i - r * RR_TW;
+              const int cy = min(max(ty0 + r - fz.epad, 0), fz.ehs - 1), cx = min(max(tx0 + c - fz.epad, 0), fz.ews - 1);
+              yv[SET][cb][it] = *reinterpret_cast<const v4u*>(ey + cb8_index(n, cbc, cy, cx, g.CBout, fz.ehs, fz.ews));
+            }
+          }
+          ecv[SET] = (f32x4){1.f, 0.f, 0.f, 0.f};
+          if (fz.ecoef && tl < 16) ecv[SET] = reinterpret_cast<const f32x4*>(fz.ecoef)[(size_t)n * g.CoutP + min(grp * 16 + tl, g.CoutP - 1)];
+        }
+      }
+    };
+    auto commit = [&](int t, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
+      int n, ty0, tx0, ck, tile;
+      stage_coords(t, n, ty0, tx0, ck, tile);
+      uint4* dst = inbuf + (t & 1) * 2 * PLANE;
+      // slots of this thread inside a plane (dead slots: their duplicate is transformed too and dropped at the store,
+      // so that the transform below is straight-line code whose dependent FMA chains the scheduler can interleave)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        uint4 v[PER];
+#pragma unroll
+        for (int it = 0; it < PER; ++it) v[it] = make_uint4(rin[SET][cb][it][0], rin[SET][cb][it][1], rin[SET][cb][it][2], rin[SET][cb][it][3]);
+        if constexpr (FUSE == 1) {
+          const int gcb = ck * 2 + cb;
+          const bool second = gcb >= g.CB0;
+          const float* ct = second ? fz.coef1 : fz.coef0;
+          const int pact = second ? fz.act1 : fz.act0;
+          if (gcb < g.CBin && (ct != nullptr || pact != MC_ACT_NONE)) {
+            float psc[8], psh[8];
+            load_coef8(ct, n, (second ? g.CB1 : g.CB0) * 8, second ? gcb - g.CB0 : gcb, psc, psh);
+#pragma unroll
+            // normalise on load.  (A/B on MI355X: the packed-f32 FMA form, 207 us at level 0, beats a single-issue-FMA form
+            // with twice the instructions, 275-290 us: the loader waves are bound by instruction issue beside the MFMAs.)
+            for (int it = 0; it < PER; ++it) v[it] = xform_bf16x8(v[it], psc, psh, GELU ? (int)MC_ACT_GELU : pact);
+            if (okm[SET] != 0xffffffffu) {                  // zero padding stays zero (border tiles of zero-padded layers only)
+#pragma unroll
+              for (int it = 0; it < PER; ++it) if (!((okm[SET] >> it) & 1u)) v[it] = make_uint4(0, 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+          if (s_rc[it] >= 0) dst[cb * PLANE + ((s_rc[it] >> 15) & 0x7fff) * TIW + (s_rc[it] & 0x7fff)] = v[it];
+      }
+      if (!w_global && (w_every || t == 0)) {
+        v4u* wd = reinterpret_cast<v4u*>(wbuf) + (w_every ? (t & 1) : 0) * NFRAG * 64;
+#pragma unroll
+        for (int it = 0; it < WPER; ++it) if (tl + it * 256 < NFRAG * 64) wd[tl + it * 256] = wv[SET][it];
+      }
+    };
+    // FUSE == 2: the y tile and the coefficients of stage t's work item (loaded with stage t's window) -> LDS, for the
+    // epilogue that follows the mid-stage barrier
+    auto put_y = [&](int t, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
+      if constexpr (FUSE == 2) {
+        if ((t % chunks) == chunks - 1) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int it = 0; it < YPER; ++it) reinterpret_cast<v4u*>(ybuf)[cb * YSLOTS + tl + it * 256] = yv[SET][cb][it];
+          if (tl < 16) reinterpret_cast<f32x4*>(ecl)[tl] = ecv[SET];
+        }
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+#ifdef MC_RR_STAMPS
+    long long st_acc[4] = {0, 0, 0, 0}, st_prev = clock64();
+#endif
+    issue(0, S0{});
+    if (total > 1) issue(1, S1{});
+    commit(0, S0{});
+    __syncthreads();
+    RR_STAMP(3);
+    for (int t = 0; t < total; t += 2) {
+      // even stage t: set 0 held stage t (already in LDS); deliver stage t + 1 from set 1
+      put_y(t, S0{});
+      if (t + 2 < total) issue(t + 2, S0{});
+      RR_STAMP(0);
+      if (FUSE == 2) __syncthreads();
+      if (t + 1 < total) commit(t + 1, S1{});
+      RR_STAMP(1);
+      __syncthreads();
+      RR_STAMP(2);
+      if (t + 1 >= total) break;
+      put_y(t + 1, S1{});
+      if (t + 3 < total) issue(t + 3, S1{});
+      RR_STAMP(0);
+      if (FUSE == 2) __syncthreads();
+      if (t + 2 < total) commit(t + 2, S0{});
+      RR_STAMP(1);
+      __syncthreads();
+      RR_STAMP(2);
+    }
+#ifdef MC_RR_STAMPS
+    if (blockIdx.x == 77 && blockIdx.y == 0 && threadIdx.x == 256)
+      printf("loader stages %d: issue %lld commit %lld barrier %lld prologue %lld\n", total, st_acc[0], st_acc[1], st_acc[2], st_acc[3]);
+#endif
+    return;
+  }
+
+  // =================================================== MFMA waves ===================================================
+  const int strip = wave;                                  // 16-column strip of the tile
+  const int m = lane & 15, gq = lane >> 4;
+  // this lane's slot offset per fragment type inside a [2][PLANE] buffer (row pair base 0)
+  int aoff[NTY];
+#pragma unroll
+  for (int T = 0; T < NTY; ++T) {
+    int rho = S::rho(T, 0), kx = S::kx(T, 0), cb = S::cb(T, 0);
+#pragma unroll
+    for (int gg = 1; gg < 4; ++gg) if (gq == gg) { rho = S::rho(T, gg); kx = S::kx(T, gg); cb = S::cb(T, gg); }
+    aoff[T] = cb * PLANE + rho * TIW + kx + strip * 16 + m;
+  }
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = grp * 16 + gq * 4 + r;
+    bv[r] = (bias && co < g.Cout) ? bias[co] : 0.f;
+  }
+  f32x4 acc[RR_R];
+  bf16x8 wf[NFRAG];
+  const int cob = grp * 2 + (gq >> 1);                      // channel block of this lane's four output channels
+  const bool cobok = cob < g.CBout;
+  const int cbc = min(cob, g.CBout - 1);
+  const int tiles4 = g.tiles * RR_STRIPS;                   // partial-sum slots per sample: one per (tile, strip)
+
+  __syncthreads();                                          // stage 0 and its filter fragments are in LDS
+#ifdef MC_RR_STAMPS
+  long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#endif
+  for (int t = 0; t < total; ++t) {
+    int n, ty0, tx0, ck, tile;
+    stage_coords(t, n, ty0, tx0, ck, tile);
+    if (ck == 0) {
+#pragma unroll
+      for (int r = 0; r < RR_R; ++r) acc[r] = (f32x4){bv[0], bv[1], bv[2], bv[3]};
+    }
+    // filter fragments of this chunk -> registers (loop invariants of the K loop; a single-chunk layer keeps them for
+    // the whole kernel, except in the input-gradient form whose epilogue needs the registers)
+    if (FUSE != 2 && chunks == 1 && t > 0) {
+    } else if (w_global) {
+      const uint4* wsrc = reinterpret_cast<const uint4*>(bank) + ((size_t)(ck * ntiles_total + grp) * NFRAG) * 64 + lane;
+#pragma unroll
+      for (int f = 0; f < NFRAG; ++f) wf[f] = __builtin_bit_cast(bf16x8, wsrc[(size_t)f * 64]);
+    } else {
+      const uint4* ws = wbuf + ((NW == 2 && chunks > 1) ? (t & 1) : 0) * NFRAG * 64 + lane;
+#pragma unroll
+      for (int f = 0; f < NFRAG; ++f) wf[f] = __builtin_bit_cast(bf16x8, ws[f * 64]);
+    }
+    RR_STAMP(0);
+    // ---- K loop: every input fragment of a row pair feeds up to K (+1) output rows.  Fragments are read three ahead
+    // of their MFMAs into a ring of four registers (an LDS read takes ~130 cycles, the 5-6 MFMAs of a fragment 80-96);
+    // the scheduling barriers keep the compiler from regrouping reads and MFMAs (it otherwise waits for every read
+    // right after issuing it).
+    const uint4* buf = inbuf + (t & 1) * 2 * PLANE;
+    constexpr int NF = (TIH / 2) * NTY, AHEAD = 3;
+    bf16x8 fr[4];
+    auto ldf = [&](int k) { return *reinterpret_cast<const bf16x8*>(buf + aoff[k % NTY] + 2 * (k / NTY) * TIW); };
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) fr[k] = ldf(k);
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      if (k + AHEAD < NF) fr[(k + AHEAD) & 3] = ldf(k + AHEAD);
+      const int T = k % NTY, i = 2 * (k / NTY);
+#pragma unroll
+      for (int kappa = S::kmin(T); kappa <= S::kmax(T); ++kappa) {
+        const int r = i - kappa;
+        if (r >= 0 && r < RR_R) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S::fidx(T, kappa)], fr[k & 3], acc[r], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    RR_STAMP(1);
+    if (FUSE == 2) __syncthreads();                         // the loaders have put this work item's y tile / coefficients
+    RR_STAMP(4);
+    if (ck == chunks - 1) {
+      // ---- epilogue: this lane holds, for pixel column ox and rows ty0 .. ty0 + 15, four consecutive output channels
+      const int ox = tx0 + strip * 16 + m;
+      f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}}, s2[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+      constexpr int esz = OUT_F32 ? 4 : 2;
+      char* dst;
+      if (g.split8 > 0 && cbc >= g.split8)
+        dst = reinterpret_cast<char*>(y1) + (cb8_index(n, cbc - g.split8, ty0, ox, g.CBout - g.split8, g.Ho, g.Wo) + (gq & 1) * 4) * esz;
+      else
+        dst = reinterpret_cast<char*>(y0) + (cb8_index(n, cbc, ty0, ox, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo) + (gq & 1) * 4) * esz;
+      const size_t row_bytes = (size_t)g.Wo * 8 * esz;
+      const bool colok = ox < g.Wo && cobok;
+      if constexpr (FUSE == 2) {
+        float csc[4], csh[4], cme[4], crs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 c4 = ecl[gq * 4 + r];
+          csc[r] = c4.x; csh[r] = c4.y; cme[r] = c4.z; crs[r] = c4.w;
+        }
+        const int p = fz.epad, fr = fz.ezero ? 0 : p + 1;
+        const int ix = ox - p;
+        const bool xfin = colok && ix >= fr && ix < fz.ews - fr;
+        const char* yb = reinterpret_cast<const char*>(ybuf + (gq >> 1) * YSLOTS + strip * 16 + m) + (gq & 1) * 8;
+#pragma unroll
+        for (int r = 0; r < RR_R; ++r) {
+          const int oy = ty0 + r, iy = oy - p;
+          const bool fin = xfin && iy >= fr && iy < fz.ehs - fr;
+          const uint2 yv = *reinterpret_cast<const uint2*>(yb + (size_t)r * RR_TW * 16);
+          const float yf[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u),
+                               __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xffff0000u)};
+          float o[4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 yy = (f32x2){yf[2 * h], yf[2 * h + 1]};
+            const f32x2 z = pk_fma(yy, (f32x2){csc[2 * h], csc[2 * h + 1]}, (f32x2){csh[2 * h], csh[2 * h + 1]});
+            f32x2 gp;
+            if (GELU || fz.eact == MC_ACT_GELU) gp = gelu_grad_poly2(z);
+            else gp = (f32x2){act_bwd(z.x, fz.eact), act_bwd(z.y, fz.eact)};
+            const f32x2 da = (f32x2){acc[r][2 * h], acc[r][2 * h + 1]};
+            const f32x2 dz = da * gp;
+            const f32x2 yh = (yy - (f32x2){cme[2 * h], cme[2 * h + 1]}) * (f32x2){crs[2 * h], crs[2 * h + 1]};
+            if (fin) { s1[h] += dz; s2[h] = pk_fma(dz, yh, s2[h]); }
+            o[2 * h] = fin ? dz.x : da.x; o[2 * h + 1] = fin ? dz.y : da.y;
+          }
+          if (colok && oy < g.Ho) {
+            *reinterpret_cast<uint2*>(dst + (size_t)r * row_bytes) = make_uint2(pk_bf16(o[0], o[1]), pk_bf16(o[2], o[3]));
+          }
+        }
+      } else if constexpr (OUT_F32) {
+#pragma unroll
+        for (int r = 0; r < RR_R; ++r) {
+          const f32x2 v01 = (f32x2){acc[r][0], acc[r][1]}, v23 = (f32x2){acc[r][2], acc[r][3]};
+          if (colok && ty0 + r < g.Ho) {
+            s1[0] += v01; s1[1] += v23;
+            s2[0] = pk_fma(v01, v01, s2[0]); s2[1] = pk_fma(v23, v23, s2[1]);
+            *reinterpret_cast<float4*>(dst + (size_t)r * row_bytes) = make_float4(v01.x, v01.y, v23.x, v23.y);
+          }
+        }
+      } else {
+        // Two output rows at a time: after v_permlane16_swap of the packed halves the lanes of the even 16-lane rows hold
+        // the whole 16-byte CB8 vector (8 channels) of output row r, the odd rows that of row r + 1 — 8 dwordx4 stores
+        // per wave instead of 16 dwordx2 (the epilogue was store-issue bound: 2300 of 6800 cycles per stage).
+        char* dst16 = dst - (gq & 1) * 4 * esz + (size_t)(gq & 1) * row_bytes;
+        auto rows = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;      // tile inside the image, both channel blocks exist: no masks
+#pragma unroll
+          for (int r = 0; r < RR_R; r += 2) {
+            const f32x2 a01 = (f32x2){acc[r][0], acc[r][1]}, a23 = (f32x2){acc[r][2], acc[r][3]};
+            const f32x2 b01 = (f32x2){acc[r + 1][0], acc[r + 1][1]}, b23 = (f32x2){acc[r + 1][2], acc[r + 1][3]};
+            if (FULL || (colok && ty0 + r < g.Ho)) {
+              s1[0] += a01; s1[1] += a23;
+              s2[0] = pk_fma(a01, a01, s2[0]); s2[1] = pk_fma(a23, a23, s2[1]);
+            }
+            if (FULL || (colok && ty0 + r + 1 < g.Ho)) {
+              s1[0] += b01; s1[1] += b23;
+              s2[0] = pk_fma(b01, b01, s2[0]); s2[1] = pk_fma(b23, b23, s2[1]);
+            }
+            const auto sx = __builtin_amdgcn_permlane16_swap(pk_bf16(a01.x, a01.y), pk_bf16(b01.x, b01.y), false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pk_bf16(a23.x, a23.y), pk_bf16(b23.x, b23.y), false, false);
+#ifdef MC_RR_NOSTORE   /* timing-only ablation: wrong results */
+            if ((FULL || (colok && ty0 + r + (gq & 1) < g.Ho)) && sx[0] == 0x12345678u)
+#else
+            if (FULL || (colok && ty0 + r + (gq & 1) < g.Ho))
+#endif
+              *reinterpret_cast<uint4*>(dst16 + (size_t)r * row_bytes) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
+        };
+        if (ty0 + RR_R <= g.Ho && tx0 + RR_TW <= g.Wo && grp * 2 + 1 < g.CBout) rows(std::true_type{});
+        else rows(std::false_type{});
+      }
+      RR_STAMP(5);
+      float* pp = FUSE == 2 ? fz.epart : part;
+      if (pp) {
+        // sum over the 16 pixel lanes of each 16-lane row with DPP row rotations (no LDS traffic: the ds_bpermute
+        // butterfly cost 660 cycles per stage); every lane ends with the totals, lane m stores value index m >> 1
+        float q8[8] = {s1[0].x, s2[0].x, s1[0].y, s2[0].y, s1[1].x, s2[1].x, s1[1].y, s2[1].y};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          q8[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q8[k]), 0x128, 0xf, 0xf, false));   // row_ror:8
+          q8[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q8[k]), 0x124, 0xf, 0xf, false));   // row_ror:4
+          q8[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q8[k]), 0x122, 0xf, 0xf, false));   // row_ror:2
+          q8[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q8[k]), 0x121, 0xf, 0xf, false));   // row_ror:1
+        }
+        float q1 = q8[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) q1 = (m >> 1) == k ? q8[k] : q1;
+        const int co = grp * 16 + gq * 4 + (m >> 2);
+        if ((m & 1) == 0 && co < g.CoutP) {
+          const size_t stride = FUSE == 2 ? (size_t)fz.estride : (size_t)tiles4;
+          pp[(((size_t)n * stride + (size_t)tile * RR_STRIPS + strip) * g.CoutP + co) * 2 + ((m >> 1) & 1)] = q1;
+        }
+      }
+    }
+    RR_STAMP(2);
+    __syncthreads();                                        // stage t consumed; stage t + 1 delivered
+    RR_STAMP(3);
+  }
+#ifdef MC_RR_STAMPS
+  if (blockIdx.x == 77 && blockIdx.y == 0 && threadIdx.x == 0)
+    printf("mfma stages %d: wload %lld kloop %lld rows %lld stats %lld barrier %lld midbarrier %lld\n", total, st_acc[0], st_acc[1], st_acc[5], st_acc[2], st_acc[3], st_acc[4]);
+#endif
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------------------------------
+bool mc_rr_applies(const ConvGeom& g) {
+  const int ntiles = (g.Cout + 15) / 16;
+  static const int on = [] { const char* e = getenv("MC_CONV_RR"); return e ? atoi(e) : 1; }();
+  return on && g.dtype == MC_BF16 && (ntiles % 2 == 1);     // one 16-channel output tile per work-group (pick_nt == 1)
+}
+
+void mc_rr_tile(int* th, int* tw) { *th = RR_R; *tw = RR_TW; }
+int mc_rr_stat_slots(const ConvGeom& g) { return g.tiles * RR_STRIPS; }
+
+static void rr_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& ntiles, int& nfrag) {
+  const int cb_in = dgrad ? g.CBout : g.CBin;
+  const int c_out = dgrad ? g.CinP : g.Cout;
+  chunks = (cb_in + 1) / 2;
+  ntiles = (c_out + 15) / 16;
+  nfrag = g.K == 5 ? RR<5>::NFRAG : RR<3>::NFRAG;
+}
+size_t mc_rr_bank_bytes(const ConvGeom& g, int dgrad) {
+  int chunks, ntiles, nfrag;
+  rr_bank_dims(g, dgrad, chunks, ntiles, nfrag);
+  return (size_t)chunks * ntiles * nfrag * 64 * 16;
+}
+int mc_rr_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hipStream_t s) {
+  int chunks, ntiles, nfrag;
+  rr_bank_dims(g, dgrad, chunks, ntiles, nfrag);
+  const size_t total = (size_t)chunks * ntiles * nfrag * 64 * 8;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_rr, dim3(blocks), dim3(256), 0, s, g, w, dgrad, (bf16_t*)packed, ntiles, total);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+const char* mc_rr_kernel_name(const ConvGeom& g, int fuse) {
+  if (g.K == 5) return g.out_f32 ? "k_conv_rr_bf16<5,f32out>" : (fuse == 2 ? "k_conv_rr_bf16<5,dz>" : (fuse == 1 ? "k_conv_rr_bf16<5,norm>" : "k_conv_rr_bf16<5>"));
+  return g.out_f32 ? "k_conv_rr_bf16<3,f32out>" : (fuse == 2 ? "k_conv_rr_bf16<3,dz>" : (fuse == 1 ? "k_conv_rr_bf16<3,norm>" : "k_conv_rr_bf16<3>"));
+}
+
+template <int K, int FUSE, bool F32, bool GELU>
+static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
+                     float* part, const ConvFuse& fz, hipStream_t s) {
+  using S = RR<K>;
+  const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (size_t)(FUSE == 2 ? 1 : 2) * S::NFRAG * 1024 +
+                     (FUSE == 2 ? (size_t)2 * RR_R * RR_TW * 16 + 256 : 0);
+  static bool attr_set = false;                              // one per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int groups = (g.Cout + 15) / 16;
+  const int items = g.tiles * g.N;
+  static const int cap_total = [] { const char* e = getenv("MC_RR_CAP"); return e ? atoi(e) : 256; }();   // one work-group per CU
+  int cap = cap_total / groups > 0 ? cap_total / groups : 1;
+  const int bx = items < cap ? items : cap;
+  hipLaunchKernelGGL((k_conv_rr_bf16<K, FUSE, F32, GELU>), dim3(bx, groups, 1), dim3(512), lds, s, g, (const bf16_t*)x0,
+                     (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, fz);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
+                 float* part, const ConvFuse& fz, int fuse, hipStream_t s) {
+  if (g.K != 5 && g.K != 3) return MC_EUNSUPPORTED;
+  if (fuse == 2 && g.out_f32) return MC_EUNSUPPORTED;
+  // GELU-only instantiations carry the inline polynomial; any other activation takes the generic-switch build
+  const bool gelu = fuse == 2 ? fz.eact == MC_ACT_GELU
+                              : ((fz.act0 == MC_ACT_GELU || (fz.act0 == MC_ACT_NONE && !fz.coef0)) &&
+                                 (fz.act1 == MC_ACT_GELU || (fz.act1 == MC_ACT_NONE && !fz.coef1)));
+#define RRL(K, FU, F32, GE) rr_launch<K, FU, F32, GE>(g, x0, x1, bank, bias, y0, y1, part, fz, s)
+#define RRK(K)                                                                                                  \
+  do {                                                                                                          \
+    if (fuse == 0) return g.out_f32 ? RRL(K, 0, true, true) : RRL(K, 0, false, true);                           \
+    if (fuse == 2) return gelu ? RRL(K, 2, false, true) : RRL(K, 2, false, false);                              \
+    if (g.out_f32) return gelu ? RRL(K, 1, true, true) : RRL(K, 1, true, false);                                \
+    return gelu ? RRL(K, 1, false, true) : RRL(K, 1, false, false);                                             \
+  } while (0)
+  if (g.K == 5) RRK(5);
+  RRK(3);
+#undef RRK
+#undef RRL
+}

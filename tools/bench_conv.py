@@ -40,7 +40,23 @@ part = torch.empty((N, tiles, ((a.cout + 7) // 8) * 8, 2), device=dev)
 wpart = torch.empty(L.call("mc_wgrad_partial_bytes", C.byref(d)), dtype=torch.uint8, device=dev)
 dw = torch.zeros_like(w); db = torch.zeros_like(b)
 flops = 2.0 * N * cin * a.cout * a.k * a.k * H * W
+# fused forms: the source is a raw conv output normalised on load; the input gradient carries the GroupNorm-backward epilogue
+cp8 = lambda c: ((c + 7) // 8) * 8
+coef0 = torch.randn((N, cp8(a.cin), 4), device=dev) * 0.1 + torch.tensor([1.0, 0.0, 0.0, 1.0], device=dev)
+pro = L.ConvPrologue(L.ptr(coef0), None, L.ACTS["gelu"], 0)
+dtiles = L.call("mc_conv_tiles", C.byref(dd))
+fb = L.call("mc_fold_blocks", H, W, pad, 2)
+epart = torch.empty((N, dtiles + fb, cp8(cin), 2), device=dev)
+ecoef = torch.randn((N, cp8(cin), 4), device=dev) * 0.1 + torch.tensor([1.0, 0.0, 0.0, 1.0], device=dev)
+epi = L.ConvEpilogue(L.ptr(x0), L.ptr(ecoef), L.ACTS["gelu"], pad, 2, H, W, L.ptr(epart), dtiles + fb)
 ops = {
+    "fwdn": (lambda: L.call("mc_conv2d_fused", C.byref(d), L.ptr(x0), L.ptr(x1), C.byref(pro), L.ptr(bank), L.ptr(b), L.ptr(y), None, L.ptr(part), None, st),
+             N * es * (cin + a.cout) * H * W),
+    "dgradz": (lambda: L.call("mc_conv2d_fused", C.byref(dd), L.ptr(dy), None, None, L.ptr(dbank), None, L.ptr(dx0), None, None, C.byref(epi), st),
+               N * es * (2 * cin + a.cout) * H * W),
+    "foldz": (lambda: L.call("mc_fold_padded_dz", L.ptr(dx0), N, cin, H, W, pad, 2, mc, L.ptr(x0), L.ptr(ecoef), L.ACTS["gelu"], L.ptr(epart), dtiles + fb, dtiles, st), 0),
+    "wgradn": (lambda: L.call("mc_conv2d_wgrad_fused", C.byref(d), L.ptr(x0), L.ptr(x1), C.byref(pro), L.ptr(dy), L.ptr(wpart), st),
+               N * es * (cin + a.cout) * H * W),
     "fwd": (lambda: L.call("mc_conv2d", C.byref(d), L.ptr(x0), L.ptr(x1), L.ptr(bank), L.ptr(b), L.ptr(y), None, L.ptr(part), st),
             N * es * (cin + a.cout) * H * W),
     "dgrad": (lambda: L.call("mc_conv2d", C.byref(dd), L.ptr(dy), None, L.ptr(dbank), None, L.ptr(dx0), L.ptr(dx1), None, st),
