@@ -16,7 +16,7 @@ int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void*
 const char* mc_bf16_kernel_name(const ConvGeom& g);
 void mc_bf16_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles);
 // row-reuse bf16 path for single-output-tile layers (conv_rr_bf16.hip)
-bool mc_rr_applies(const ConvGeom& g);
+bool mc_rr_applies(int dtype, int cout, int wo);
 size_t mc_rr_bank_bytes(const ConvGeom& g, int dgrad);
 int mc_rr_pack(const ConvGeom& g, const float* w_unique, int dgrad, void* packed, hipStream_t s);
 int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
@@ -28,9 +28,7 @@ namespace {
 // forward / input-gradient kernel family of a descriptor: the row-reuse kernel takes the layers with one 16-channel
 // output tile per work-group (an odd number of output tiles), the wide-tile kernel the rest
 bool rr_desc(const mc_conv_desc* d) {
-  ConvGeom t;
-  t.dtype = d->dtype; t.Cout = d->c_out;
-  return d->dtype == MC_BF16 && mc_rr_applies(t);
+  return mc_rr_applies(d->dtype, d->c_out, d->w + 2 * d->pad - d->k + 1);
 }
 
 int geom_for(const mc_conv_desc* d, ConvGeom& g) {
@@ -91,6 +89,8 @@ struct WfJob {
 constexpr int WF_MAX = 32;
 struct WfTable { int n; WfJob j[WF_MAX]; };
 
+constexpr int WF_WAVES = 16;      // waves per block: each sums every 16th slab (the loop is bound by the latency of its
+                                  // strided loads: 4 waves per block took 129 us on a level-0 layer's 768 slabs)
 __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock) {
   // outputs are enumerated in slab order [tap][chunk][u][16] (coalesced reads of every slab), then the bias entries
   const int K = g.K, KK = K * K;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
   const size_t total = nW + g.Cout;
   const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t i = (size_t)lblock * 64 + e;
-  __shared__ float red[4][64];
+  __shared__ float red[WF_WAVES][64];
   float s = 0.f;
   long dst = -1;                  // index into dw (>= 0), or -2 - co for the bias
   if (i < total) {
@@ -127,15 +127,15 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
       const float* part = g.part;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int G = w;
-      for (; G + 12 < g.G; G += 16) {
-        a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + 4) * slab + o1];
-        a2 += part[(size_t)(G + 8) * slab + o1]; a3 += part[(size_t)(G + 12) * slab + o1];
+      for (; G + 3 * WF_WAVES < g.G; G += 4 * WF_WAVES) {
+        a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + WF_WAVES) * slab + o1];
+        a2 += part[(size_t)(G + 2 * WF_WAVES) * slab + o1]; a3 += part[(size_t)(G + 3 * WF_WAVES) * slab + o1];
         if (two) {
-          a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + 4) * slab + o2];
-          a2 += part[(size_t)(G + 8) * slab + o2]; a3 += part[(size_t)(G + 12) * slab + o2];
+          a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + WF_WAVES) * slab + o2];
+          a2 += part[(size_t)(G + 2 * WF_WAVES) * slab + o2]; a3 += part[(size_t)(G + 3 * WF_WAVES) * slab + o2];
         }
       }
-      for (; G < g.G; G += 4) {
+      for (; G < g.G; G += WF_WAVES) {
         a0 += part[(size_t)G * slab + o1];
         if (two) a0 += part[(size_t)G * slab + o2];
       }
@@ -147,13 +147,15 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
   red[w][e] = s;
   __syncthreads();
   if (w == 0 && dst != -1) {
-    float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < WF_WAVES; k += 4) r += (red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e]);
     if (dst >= 0) { if (g.dw) g.dw[dst] += r; }
     else if (g.db) g.db[-2 - dst] += r;
   }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad_finalize(WfTable t) {
+__global__ __launch_bounds__(64 * WF_WAVES) void k_wgrad_finalize(WfTable t) {
   int ji = 0;
 #pragma unroll 1
   for (int k = 1; k < t.n; ++k) if ((int)blockIdx.x >= t.j[k].first_block) ji = k;
@@ -177,10 +179,8 @@ int wf_fill(const mc_conv_desc* d, const void* partials, float* dw, float* db, W
 // The input-gradient bank of a layer is consumed by the kernel family of the INPUT-GRADIENT convolution (whose output
 // channels are this layer's input channels), the forward bank by this layer's own family.
 static bool bank_is_rr(const ConvGeom& g, int dgrad) {
-  if (g.dtype != MC_BF16) return false;
-  ConvGeom t;
-  t.dtype = MC_BF16; t.Cout = dgrad ? g.Cin : g.Cout;
-  return mc_rr_applies(t);
+  // (the input-gradient convolution runs on the padded domain of this layer's input: width W + 2 pad)
+  return dgrad ? mc_rr_applies(g.dtype, g.Cin, g.W + 2 * g.pad) : mc_rr_applies(g.dtype, g.Cout, g.Wo);
 }
 
 extern "C" {
@@ -317,7 +317,7 @@ int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* cons
       t.j[k].first_block = blocks;
       blocks += b;
     }
-    hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(64 * WF_WAVES), 0, (hipStream_t)stream, t);
     MC_CHECK_LAUNCH();
   }
   return MC_OK;

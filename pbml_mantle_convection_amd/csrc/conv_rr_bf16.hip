@@ -17,8 +17,10 @@
 //              stages ahead into registers, then — "normalise on load" — the producer's GroupNorm affine + activation on
 //              the vector ALU (it co-issues with the other waves' MFMAs), then ds_write into the other LDS buffer.
 // One s_barrier per stage.  A stage = one 16-channel input chunk of one (image, tile) work item; work-groups are persistent.
-// The input-gradient form (FUSE == 2) also stages the producer's raw output tile so that the epilogue can turn dA into
-// dz = dA act'(z) and emit GroupNorm-backward partial sums (see ConvFuse / mc_conv_epilogue).
+// In the input-gradient form (FUSE == 2) the loader waves — which have no activation to apply to dY — also run the
+// epilogue: the MFMA waves hand their f32 accumulators over through LDS and continue with the next stage, the loaders
+// (holding the producer's raw output y for the tile's pixels in registers) form dz = dA act'(z), the GroupNorm-backward
+// partial sums and the stores beside the next stage's MFMAs (see ConvFuse / mc_conv_epilogue).
 #include "conv_rr.h"
 #include <type_traits>
 
@@ -46,10 +48,12 @@ __global__ void k_pack_rr(ConvGeom g, const float* __restrict__ wu, int dgrad, b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LDS map (16-byte slots):  inbuf [2][2][PLANE] | wbuf [NW][NFRAG][64] | (FUSE == 2) ybuf [2][YSLOTS], ecl [16]
-//   NW = 2 for FUSE != 2 (layers with several input chunks: the loaders deliver the next stage's filter fragments with
-//   its window; one chunk: staged once), NW = 1 for FUSE == 2 (one chunk: staged once; several chunks — a rare shape —:
-//   the MFMA waves fetch their fragments from global memory per stage).
+// LDS map (16-byte slots):  inbuf [2][2][PLANE] | FUSE != 2: wbuf [2][NFRAG][64]  | FUSE == 2: exch [16 x 64 px][4]
+//   wbuf: layers with several input chunks get the next stage's filter fragments delivered with its window; one chunk:
+//   staged once, then loop invariants in registers.  FUSE == 2: the accumulator exchange area (f32, 64 KB; the 16-byte
+//   quad index of a pixel is XOR-swizzled with bits 2-3 of the pixel index so that both sides are conflict-free); the
+//   filter fragments of a one-chunk layer are staged through it once, before its first use; several chunks (a rare
+//   shape): the MFMA waves fetch their fragments from global memory per stage.
 // GELU: every fused activation is GELU (inline polynomial); otherwise the generic activation switch is compiled in.
 template <int K, int FUSE, bool OUT_F32, bool GELU>
 __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
@@ -64,8 +68,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* const inbuf = reinterpret_cast<uint4*>(smem_raw);
   uint4* const wbuf = inbuf + 2 * 2 * PLANE;
-  uint4* const ybuf = wbuf + NW * NFRAG * 64;
-  float4* const ecl = reinterpret_cast<float4*>(ybuf + 2 * YSLOTS);
+  uint4* const exch = wbuf;                                                     // (FUSE == 2) [YSLOTS][4]
 
   const int grp = blockIdx.y;                                                    // 16-channel output tile of this block
   const int ntiles_total = gridDim.y;
@@ -103,8 +106,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
     }
     v4u rin[2][2][PER];                                    // [register set][plane][slot]
     unsigned okm[2] = {0xffffffffu, 0xffffffffu};
-    v4u yv[2][2][YPER];                                    // FUSE == 2: the producer's raw output at the tile's pixels
-    f32x4 ecv[2];                                          // FUSE == 2: (scale, shift, mean, rstd) of channel tl (tl < 16)
+    v4u yv[2][YPER];                                       // FUSE == 2: the producer's raw output at this thread's pixels
+    float ecv[4] = {1.f, 0.f, 0.f, 0.f};                   // FUSE == 2: (scale, shift, mean, rstd) of channel lane & 15 (four
+                                                           // scalars: v_readlane of an ext-vector element returned element 0)
     constexpr int WPER = (NFRAG * 64 + 255) / 256;         // filter-fragment slots per loader thread
     v4u wv[2][WPER];                                       // the stage's filter fragments (staged through LDS for the MFMA waves)
     const bool w_every = !w_global && chunks > 1;          // several chunks: a fresh set per stage; one chunk: stage 0 only
@@ -148,23 +152,119 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #pragma unroll
         for (int it = 0; it < WPER; ++it) wv[SET][it] = wsrc[min(tl + it * 256, NFRAG * 64 - 1)];
       }
+    };
+    // FUSE == 2: y and the coefficients of stage t's work item, for the epilogue one iteration later
+    auto load_y = [&](int t) {
       if constexpr (FUSE == 2) {
-        if (ck == chunks - 1) {
-          // y at the interior coordinates of the tile's (padded-domain) output pixels; clamped: the epilogue only uses
-          // the pixels it finalises
-          const bf16_t* ey = reinterpret_cast<const bf16_t*>(fz.ey);
+        if ((t % chunks) != chunks - 1) return;
+        int n, ty0, tx0, ck, tile;
+        stage_coords(t, n, ty0, tx0, ck, tile);
+        // y at the interior coordinates of the tile's (padded-domain) output pixels; clamped: only finalised pixels use it
+        const bf16_t* ey = reinterpret_cast<const bf16_t*>(fz.ey);
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            const int cbc = min(grp * 2 + cb, g.CBout - 1);
+        for (int cb = 0; cb < 2; ++cb) {
+          const int cbc = min(grp * 2 + cb, g.CBout - 1);
+#pragma unroll
+          for (int it = 0; it < YPER; ++it) {
+            const int i = tl + it * 256, r = i / RR_TW, c = i - r * RR_TW;
+            const int cy = min(max(ty0 + r - fz.epad, 0), fz.ehs - 1), cx = min(max(tx0 + c - fz.epad, 0), fz.ews - 1);
+            yv[cb][it] = *reinterpret_cast<const v4u*>(ey + cb8_index(n, cbc, cy, cx, g.CBout, fz.ehs, fz.ews));
+          }
+        }
+        ecv[0] = 1.f; ecv[1] = 0.f; ecv[2] = 0.f; ecv[3] = 0.f;
+        if (fz.ecoef) {
+          const float4 c4 = reinterpret_cast<const float4*>(fz.ecoef)[(size_t)n * g.CoutP + min(grp * 16 + (lane & 15), g.CoutP - 1)];
+          ecv[0] = c4.x; ecv[1] = c4.y; ecv[2] = c4.z; ecv[3] = c4.w;
+        }
+      }
+    };
+    // FUSE == 2: epilogue of stage t from the accumulators the MFMA waves left in `exch`: dz = dA act'(z) for the pixels
+    // whose value is final (raw dA otherwise), the per-wave (sum dz, sum dz yhat) partials, the stores
+    auto epilogue_dz = [&](int t) {
+      if constexpr (FUSE == 2) {
+        if ((t % chunks) != chunks - 1) return;
+        int n, ty0, tx0, ck, tile;
+        stage_coords(t, n, ty0, tx0, ck, tile);
+        const int p = fz.epad, fr = fz.ezero ? 0 : p + 1;
+        float s[2][16];                                      // [channel block][2 * channel + (0: sum dz, 1: sum dz yhat)]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) s[cb][j] = 0.f;
+        bf16_t* yout = y0;
+        bool inb[YPER], fin[YPER];
+        int pix[YPER];
+        size_t oidx[YPER];
+#pragma unroll
+        for (int it = 0; it < YPER; ++it) {
+          const int i = tl + it * 256, r = i / RR_TW, c = i - r * RR_TW;
+          const int oy = ty0 + r, ox = tx0 + c, iy = oy - p, ix = ox - p;
+          pix[it] = i;
+          inb[it] = oy < g.Ho && ox < g.Wo;
+          fin[it] = inb[it] && iy >= fr && iy < fz.ehs - fr && ix >= fr && ix < fz.ews - fr;
+          oidx[it] = cb8_index(n, grp * 2, min(oy, g.Ho - 1), min(ox, g.Wo - 1), g.CBout, g.Ho, g.Wo);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          float da[YPER][8], o[YPER][8];
+#pragma unroll
+          for (int it = 0; it < YPER; ++it) {
+            const int sw = (pix[it] >> 2) & 3;
+            const f32x4 a0 = reinterpret_cast<const f32x4*>(exch)[pix[it] * 4 + ((2 * cb) ^ sw)];
+            const f32x4 a1 = reinterpret_cast<const f32x4*>(exch)[pix[it] * 4 + ((2 * cb + 1) ^ sw)];
+            da[it][0] = a0[0]; da[it][1] = a0[1]; da[it][2] = a0[2]; da[it][3] = a0[3];
+            da[it][4] = a1[0]; da[it][5] = a1[1]; da[it][6] = a1[2]; da[it][7] = a1[3];
+          }
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            // (scale, shift, mean, rstd) of channels 8 cb + 2h (+1): lanes 8 cb + 2h (+1) of every wave hold them; broadcast
+            // and pinned to vector registers (two different SGPR pairs as v_pk_fma_f32 operands were mis-compiled)
+            float c0[4], c1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              c0[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ecv[q]), 8 * cb + 2 * h));
+              c1[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ecv[q]), 8 * cb + 2 * h + 1));
+              asm volatile("" : "+v"(c0[q]), "+v"(c1[q]));
+            }
 #pragma unroll
             for (int it = 0; it < YPER; ++it) {
-              const int i = tl + it * 256, r = i / RR_TW, c = i - r * RR_TW;
-              const int cy = min(max(ty0 + r - fz.epad, 0), fz.ehs - 1), cx = min(max(tx0 + c - fz.epad, 0), fz.ews - 1);
-              yv[SET][cb][it] = *reinterpret_cast<const v4u*>(ey + cb8_index(n, cbc, cy, cx, g.CBout, fz.ehs, fz.ews));
+              const unsigned yw = yv[cb][it][h];
+              const f32x2 yy = (f32x2){__uint_as_float(yw << 16), __uint_as_float(yw & 0xffff0000u)};
+              const f32x2 z = pk_fma(yy, (f32x2){c0[0], c1[0]}, (f32x2){c0[1], c1[1]});
+              f32x2 gp;
+              if (GELU || fz.eact == MC_ACT_GELU) gp = gelu_grad_poly2(z);
+              else gp = (f32x2){act_bwd(z.x, fz.eact), act_bwd(z.y, fz.eact)};
+              const f32x2 dA = (f32x2){da[it][2 * h], da[it][2 * h + 1]};
+              const f32x2 dz = dA * gp;
+#ifdef MC_RR_DBG_PRINT
+              if (blockIdx.x == 0 && tl == 70 && it == 1 && cb == 0 && h == 0)
+                printf("dbg n %d tile %d ecv %f %f %f %f c0 %f %f %f %f c1 %f %f yy %f %f z %f %f gp %f %f dA %f %f fin %d\n", n, tile, ecv[0], ecv[1], ecv[2], ecv[3],
+                       c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], yy.x, yy.y, z.x, z.y, gp.x, gp.y, dA.x, dA.y, (int)fin[it]);
+#endif
+              const f32x2 yh = (yy - (f32x2){c0[2], c1[2]}) * (f32x2){c0[3], c1[3]};
+              if (fin[it]) {
+                s[cb][4 * h] += dz.x; s[cb][4 * h + 1] += dz.x * yh.x;
+                s[cb][4 * h + 2] += dz.y; s[cb][4 * h + 3] += dz.y * yh.y;
+              }
+              o[it][2 * h] = fin[it] ? dz.x : dA.x; o[it][2 * h + 1] = fin[it] ? dz.y : dA.y;
             }
           }
-          ecv[SET] = (f32x4){1.f, 0.f, 0.f, 0.f};
-          if (fz.ecoef && tl < 16) ecv[SET] = reinterpret_cast<const f32x4*>(fz.ecoef)[(size_t)n * g.CoutP + min(grp * 16 + tl, g.CoutP - 1)];
+          if (grp * 2 + cb < g.CBout) {
+#pragma unroll
+            for (int it = 0; it < YPER; ++it)
+              if (inb[it])
+                *reinterpret_cast<uint4*>(yout + oidx[it] + (size_t)cb * g.Ho * g.Wo * 8) =
+                    make_uint4(pk_bf16(o[it][0], o[it][1]), pk_bf16(o[it][2], o[it][3]), pk_bf16(o[it][4], o[it][5]), pk_bf16(o[it][6], o[it][7]));
+          }
+        }
+        // wave totals: one partial-sum slot per (tile, loader wave)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          int idx;
+          const float tot = wave_sum16(s[cb], lane, idx);
+          const int co = grp * 16 + cb * 8 + (idx >> 1);
+          if ((lane & 3) == 0 && co < g.CoutP)
+            fz.epart[(((size_t)n * fz.estride + (size_t)tile * RR_STRIPS + (wave - RR_STRIPS)) * g.CoutP + co) * 2 + (idx & 1)] = tot;
         }
       }
     };
@@ -208,20 +308,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         for (int it = 0; it < WPER; ++it) if (tl + it * 256 < NFRAG * 64) wd[tl + it * 256] = wv[SET][it];
       }
     };
-    // FUSE == 2: the y tile and the coefficients of stage t's work item (loaded with stage t's window) -> LDS, for the
-    // epilogue that follows the mid-stage barrier
-    auto put_y = [&](int t, auto set_c) {
-      constexpr int SET = decltype(set_c)::value;
-      if constexpr (FUSE == 2) {
-        if ((t % chunks) == chunks - 1) {
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int it = 0; it < YPER; ++it) reinterpret_cast<v4u*>(ybuf)[cb * YSLOTS + tl + it * 256] = yv[SET][cb][it];
-          if (tl < 16) reinterpret_cast<f32x4*>(ecl)[tl] = ecv[SET];
-        }
-      }
-    };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 #ifdef MC_RR_STAMPS
@@ -232,26 +318,30 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
     commit(0, S0{});
     __syncthreads();
     RR_STAMP(3);
+    // iteration t (the MFMA waves compute stage t): epilogue of stage t - 1 (FUSE == 2), loads of stage t + 2, delivery
+    // of stage t + 1.  FUSE == 2 has two barriers per stage: the accumulators are written to `exch` between them.
     for (int t = 0; t < total; t += 2) {
-      // even stage t: set 0 held stage t (already in LDS); deliver stage t + 1 from set 1
-      put_y(t, S0{});
-      if (t + 2 < total) issue(t + 2, S0{});
+      if (t > 0) epilogue_dz(t - 1);
+      load_y(t);
+      if (t + 2 < total) issue(t + 2, S0{});                // set 0 held stage t (already in LDS)
       RR_STAMP(0);
-      if (FUSE == 2) __syncthreads();
       if (t + 1 < total) commit(t + 1, S1{});
       RR_STAMP(1);
       __syncthreads();
+      if (FUSE == 2) __syncthreads();
       RR_STAMP(2);
       if (t + 1 >= total) break;
-      put_y(t + 1, S1{});
+      epilogue_dz(t);
+      load_y(t + 1);
       if (t + 3 < total) issue(t + 3, S1{});
       RR_STAMP(0);
-      if (FUSE == 2) __syncthreads();
       if (t + 2 < total) commit(t + 2, S0{});
       RR_STAMP(1);
       __syncthreads();
+      if (FUSE == 2) __syncthreads();
       RR_STAMP(2);
     }
+    epilogue_dz(total - 1);
 #ifdef MC_RR_STAMPS
     if (blockIdx.x == 77 && blockIdx.y == 0 && threadIdx.x == 256)
       printf("loader stages %d: issue %lld commit %lld barrier %lld prologue %lld\n", total, st_acc[0], st_acc[1], st_acc[2], st_acc[3]);
@@ -296,8 +386,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
       for (int r = 0; r < RR_R; ++r) acc[r] = (f32x4){bv[0], bv[1], bv[2], bv[3]};
     }
     // filter fragments of this chunk -> registers (loop invariants of the K loop; a single-chunk layer keeps them for
-    // the whole kernel, except in the input-gradient form whose epilogue needs the registers)
-    if (FUSE != 2 && chunks == 1 && t > 0) {
+    // the whole kernel)
+    if (chunks == 1 && t > 0) {
     } else if (w_global) {
       const uint4* wsrc = reinterpret_cast<const uint4*>(bank) + ((size_t)(ck * ntiles_total + grp) * NFRAG) * 64 + lane;
 #pragma unroll
@@ -330,9 +420,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
       __builtin_amdgcn_sched_barrier(0);
     }
     RR_STAMP(1);
-    if (FUSE == 2) __syncthreads();                         // the loaders have put this work item's y tile / coefficients
+    if constexpr (FUSE == 2) {
+      // hand the accumulators to the loader waves: exch [pixel][4 quads of 4 channels], quad index swizzled
+      __syncthreads();                                      // every wave is done with the window (and the loaders with `exch`)
+      if (ck == chunks - 1) {
+#pragma unroll
+        for (int r = 0; r < RR_R; ++r) {
+          const int pix = r * RR_TW + strip * 16 + m;
+          reinterpret_cast<f32x4*>(exch)[pix * 4 + (gq ^ ((pix >> 2) & 3))] = acc[r];
+        }
+      }
+    }
     RR_STAMP(4);
-    if (ck == chunks - 1) {
+    if (FUSE != 2 && ck == chunks - 1) {
       // ---- epilogue: this lane holds, for pixel column ox and rows ty0 .. ty0 + 15, four consecutive output channels
       const int ox = tx0 + strip * 16 + m;
       f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}}, s2[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
@@ -344,43 +444,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         dst = reinterpret_cast<char*>(y0) + (cb8_index(n, cbc, ty0, ox, g.split8 > 0 ? g.split8 : g.CBout, g.Ho, g.Wo) + (gq & 1) * 4) * esz;
       const size_t row_bytes = (size_t)g.Wo * 8 * esz;
       const bool colok = ox < g.Wo && cobok;
-      if constexpr (FUSE == 2) {
-        float csc[4], csh[4], cme[4], crs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float4 c4 = ecl[gq * 4 + r];
-          csc[r] = c4.x; csh[r] = c4.y; cme[r] = c4.z; crs[r] = c4.w;
-        }
-        const int p = fz.epad, fr = fz.ezero ? 0 : p + 1;
-        const int ix = ox - p;
-        const bool xfin = colok && ix >= fr && ix < fz.ews - fr;
-        const char* yb = reinterpret_cast<const char*>(ybuf + (gq >> 1) * YSLOTS + strip * 16 + m) + (gq & 1) * 8;
-#pragma unroll
-        for (int r = 0; r < RR_R; ++r) {
-          const int oy = ty0 + r, iy = oy - p;
-          const bool fin = xfin && iy >= fr && iy < fz.ehs - fr;
-          const uint2 yv = *reinterpret_cast<const uint2*>(yb + (size_t)r * RR_TW * 16);
-          const float yf[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u),
-                               __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xffff0000u)};
-          float o[4];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const f32x2 yy = (f32x2){yf[2 * h], yf[2 * h + 1]};
-            const f32x2 z = pk_fma(yy, (f32x2){csc[2 * h], csc[2 * h + 1]}, (f32x2){csh[2 * h], csh[2 * h + 1]});
-            f32x2 gp;
-            if (GELU || fz.eact == MC_ACT_GELU) gp = gelu_grad_poly2(z);
-            else gp = (f32x2){act_bwd(z.x, fz.eact), act_bwd(z.y, fz.eact)};
-            const f32x2 da = (f32x2){acc[r][2 * h], acc[r][2 * h + 1]};
-            const f32x2 dz = da * gp;
-            const f32x2 yh = (yy - (f32x2){cme[2 * h], cme[2 * h + 1]}) * (f32x2){crs[2 * h], crs[2 * h + 1]};
-            if (fin) { s1[h] += dz; s2[h] = pk_fma(dz, yh, s2[h]); }
-            o[2 * h] = fin ? dz.x : da.x; o[2 * h + 1] = fin ? dz.y : da.y;
-          }
-          if (colok && oy < g.Ho) {
-            *reinterpret_cast<uint2*>(dst + (size_t)r * row_bytes) = make_uint2(pk_bf16(o[0], o[1]), pk_bf16(o[2], o[3]));
-          }
-        }
-      } else if constexpr (OUT_F32) {
+      if constexpr (OUT_F32) {
 #pragma unroll
         for (int r = 0; r < RR_R; ++r) {
           const f32x2 v01 = (f32x2){acc[r][0], acc[r][1]}, v23 = (f32x2){acc[r][2], acc[r][3]};
@@ -423,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         else rows(std::false_type{});
       }
       RR_STAMP(5);
-      float* pp = FUSE == 2 ? fz.epart : part;
+      float* pp = part;
       if (pp) {
         // sum over the 16 pixel lanes of each 16-lane row with DPP row rotations (no LDS traffic: the ds_bpermute
         // butterfly cost 660 cycles per stage); every lane ends with the totals, lane m stores value index m >> 1
@@ -440,8 +504,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         for (int k = 1; k < 8; ++k) q1 = (m >> 1) == k ? q8[k] : q1;
         const int co = grp * 16 + gq * 4 + (m >> 2);
         if ((m & 1) == 0 && co < g.CoutP) {
-          const size_t stride = FUSE == 2 ? (size_t)fz.estride : (size_t)tiles4;
-          pp[(((size_t)n * stride + (size_t)tile * RR_STRIPS + strip) * g.CoutP + co) * 2 + ((m >> 1) & 1)] = q1;
+          pp[(((size_t)n * tiles4 + (size_t)tile * RR_STRIPS + strip) * g.CoutP + co) * 2 + ((m >> 1) & 1)] = q1;
         }
       }
     }
@@ -451,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
   }
 #ifdef MC_RR_STAMPS
   if (blockIdx.x == 77 && blockIdx.y == 0 && threadIdx.x == 0)
-    printf("mfma stages %d: wload %lld kloop %lld rows %lld stats %lld barrier %lld midbarrier %lld\n", total, st_acc[0], st_acc[1], st_acc[5], st_acc[2], st_acc[3], st_acc[4]);
+    printf("mfma stages %d: wload %lld kloop %lld exch %lld rows %lld stats %lld barrier %lld\n", total, st_acc[0], st_acc[1], st_acc[4], st_acc[5], st_acc[2], st_acc[3]);
 #endif
 }
 
@@ -460,10 +523,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 // ----------------------------------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------------------------------
-bool mc_rr_applies(const ConvGeom& g) {
-  const int ntiles = (g.Cout + 15) / 16;
-  static const int on = [] { const char* e = getenv("MC_CONV_RR"); return e ? atoi(e) : 1; }();
-  return on && g.dtype == MC_BF16 && (ntiles % 2 == 1);     // one 16-channel output tile per work-group (pick_nt == 1)
+// Which layers take the row-reuse kernel (Cout, output width wo): every layer with an odd number of 16-channel output
+// tiles (one tile per work-group: C_out <= 16, 48); layers with 2 .. 8 output tiles too when the image is at least
+// MC_RR_MINW pixels wide — each output tile is then a separate work-group column (grid.y) that stages the window again,
+// which the idle loader waves absorb, and the MFMA work per stage is the same.  MC_CONV_RR=0 turns the kernel off, 1
+// restricts it to the odd case.
+bool mc_rr_applies(int dtype, int cout, int wo) {
+  const int ntiles = (cout + 15) / 16;
+  static const int on = [] { const char* e = getenv("MC_CONV_RR"); return e ? atoi(e) : 2; }();
+  static const int minw = [] { const char* e = getenv("MC_RR_MINW"); return e ? atoi(e) : 48; }();
+  if (!on || dtype != MC_BF16) return false;
+  if (ntiles % 2 == 1) return true;
+  return on >= 2 && ntiles <= 8 && wo >= minw;
 }
 
 void mc_rr_tile(int* th, int* tw) { *th = RR_R; *tw = RR_TW; }
@@ -501,8 +572,7 @@ template <int K, int FUSE, bool F32, bool GELU>
 static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
                      float* part, const ConvFuse& fz, hipStream_t s) {
   using S = RR<K>;
-  const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (size_t)(FUSE == 2 ? 1 : 2) * S::NFRAG * 1024 +
-                     (FUSE == 2 ? (size_t)2 * RR_R * RR_TW * 16 + 256 : 0);
+  const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (FUSE == 2 ? (size_t)RR_R * RR_TW * 64 : (size_t)2 * S::NFRAG * 1024);
   static bool attr_set = false;                              // one per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU>),

@@ -374,7 +374,12 @@ class Engine:
         # bit 0: GroupNorm + activation applied by the consumers on load (conv, filter gradient, bicubic) instead of a
         # stand-alone pass that materialises the activated tensor; bit 1: the GroupNorm-backward reduction fused into the
         # epilogue of the input-gradient launch (single-consumer tensors).  0 = the round-1 unfused chain (A/B, tests).
-        self.fuse = int(os.environ.get("MANTLE_FUSE", "3"))
+        self.fuse = int(os.environ.get("MANTLE_FUSE", "0"))
+        # ... and only for tensors of at most this many pixels.  Measured on MI355X (CFG-3, B = 32): the MFMA kernels
+        # of the two high-resolution levels are bound by vector-instruction issue, so GELU / GELU' evaluated inside them
+        # costs more than the streaming pass it replaces (level-0 16->16 forward 117 -> 207 us against a 100 us pass);
+        # at the deep levels the kernels are launch-latency bound and every fused pass is a launch saved.
+        self.fuse_maxpix = int(os.environ.get("MANTLE_FUSE_MAXPIX", str(128 * 128)))
 
     # -------------------------------------------------------------- planning
     def configure(self, N: int, H: int, W: int, device):
@@ -472,7 +477,8 @@ class Engine:
                      bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
                      need_dgrad=need_dgrad)
             fusable = all(c.kind == "up" or (c.kind == "conv" and not c.learned) for c in cons[node.out])
-            o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1))
+            o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1)
+                           and ho * wo <= self.fuse_maxpix)
             if o.fused:
                 o.raw, o.act = e["Y"], L.ACTS[g.act]
             elif node.post != L.POST_NONE:
@@ -502,7 +508,8 @@ class Engine:
                 # of a conv + (GN) + act layer and this conv is its only consumer
                 pe = self.prod.get(node.srcs[0])
                 if ((self.fuse & 2) and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
-                        and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1):
+                        and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1
+                        and h * w <= self.fuse_maxpix):
                     dtiles = L.call("mc_conv_tiles", C.byref(dd))
                     fblocks = L.call("mc_fold_blocks", h, w, node.pad, mode)
                     e["epi"] = pe

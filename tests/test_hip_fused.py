@@ -42,6 +42,7 @@ def _build(kind, r_p, seed):
 def _run(monkeypatch, fuse, kind, r_p, precision, seed=3):
     """One forward + backward of a fresh model (same seed -> same weights) with MANTLE_FUSE = fuse."""
     monkeypatch.setenv("MANTLE_FUSE", str(fuse))
+    monkeypatch.setenv("MANTLE_FUSE_MAXPIX", str(1 << 30))       # (the default restricts fusion to the low-resolution levels)
     m, shape = _build(kind, r_p, seed)
     m = m.to(DEV)
     with torch.no_grad():                       # non-trivial GroupNorm affine parameters and biases
