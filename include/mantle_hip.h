@@ -199,12 +199,6 @@ int mc_gn_finalize(const float* stat_partials, int32_t n, int32_t tiles, int32_t
  * ("normalise on load"): scale = rstd * gamma, shift = beta - mean * rstd * gamma. */
 int mc_gn_finalize_coef(const float* stat_partials, int32_t n, int32_t tiles, int32_t c, int32_t groups, int32_t hw,
                         float eps, const float* gamma, const float* beta, float* stats_ng2, float* coef4, void* stream);
-/* Traversal direction of the launches that follow (process-wide, read at launch time, so a HIP-graph capture records it per
- * kernel): reverse != 0 makes the batch-streaming kernels (mc_conv2d, mc_conv2d_wgrad in bf16 mode, mc_gn_act_fwd,
- * mc_gn_act_bwd_reduce / _apply) walk their samples / work items from the last to the first.  Results are identical; a
- * consumer that runs opposite to its producer starts on the bytes written last, which are still in the 256 MiB Infinity
- * Cache.  No counterpart in the reference (scheduling only). */
-int mc_set_direction(int32_t reverse);
 
 /* a = act(GN(y));  post = MC_POST_*.  pool > 1 additionally writes AvgPool2d(pool)(a) into
  * pooled (Unet :2002, ConvAE :1051).  y, a, pooled are CB8 of `dtype`.  a may be NULL when pool > 1: only the pooled
@@ -214,7 +208,7 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
                   int32_t act, int32_t pool, int32_t dtype, void* a, void* pooled, void* stream);
 /* Backward of act(GN(y)) given the gradient sources of a.  Phase 1 reduces
  * (sum dz, sum dz*yhat) per (n,c) into partials [n][blocks][c8*8][2]; phase 2 (finalize)
- * turns them into per-(n,g) means and accumulates dgamma/dbeta; phase 3 writes dy. */
+ * turns them into per-(n,g) means and accumulates dgamma/dbeta (in sample order: deterministic); phase 3 writes dy. */
 int32_t mc_gn_bwd_blocks(int32_t h, int32_t w);
 int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                          const float* stats_ng2, const float* gamma, const float* beta, int32_t post,
@@ -232,13 +226,6 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
  * (activation-only layer) dy = dz.  dz is read through a gradient source (MC_GSRC_PADFOLD or MC_GSRC_PLAIN). */
 int mc_gn_bwd_apply_dz(const mc_grad_src* dz, const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                        const float* coef, const float* m12_ng2, int32_t dtype, void* dy, void* stream);
-/* Phases 2 + 3 in one launch: every workgroup re-derives its groups' (m1, m2) from the phase-1 partials
- * (blocks x channels, L2-resident) and the first workgroup of each (n, channel block) accumulates dgamma/dbeta. */
-int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                              const float* stats_ng2, const float* partials, int32_t blocks, const float* gamma,
-                              const float* beta, int32_t act, int32_t dtype, const mc_grad_src* g0,
-                              const mc_grad_src* g1, float* dgamma, float* dbeta, void* dy, void* stream);
-
 /* ---- torch.cat of more than two operands along channels (NewFluidNet.forward, pytorch_networks_convae.py:1327-1332):
  * out [n][sum of blocks][h][w][8]; every operand but the last must have a multiple of 8 channels. */
 int mc_concat_cb8(const void* const* srcs, const int32_t* src_c, int32_t n_src, int32_t n, int32_t h, int32_t w,
@@ -302,7 +289,8 @@ typedef struct {
   int32_t loss_derivative; /* Trainer.loss_derivative                                      */
   int32_t l2;              /* 0: L1 (reference); 1: squared error for the data terms       */
   float lambda_mom;        /* weight of the momentum residual term (0 = off)               */
-  float inv_h;             /* 1/h of the momentum residual (126)                           */
+  float inv_h;             /* 1/h of the momentum residual (126).  NOT used by the derivative */
+                           /* terms: their x126 is the reference's literal (multigpu.py:163-166) */
   float ra;                /* Rayleigh number in the buoyancy term (1)                     */
   int32_t t_grad;          /* 1: T is a network output (gets a gradient); 0: T is given;   */
                            /* -1: the network has no temperature output (FluidNet family,  */

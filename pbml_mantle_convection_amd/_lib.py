@@ -59,7 +59,6 @@ SIGNATURES = {
     "mc_unpack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
-    "mc_set_direction": (C.c_int, [_i32]),
     "mc_packed_weight_bytes": (_sz, [_CD, _i32]),
     "mc_pack_weights": (C.c_int, [_CD, _vp, _i32, _vp, _vp]),
     "mc_conv_tiles": (_i32, [_CD]),
@@ -89,8 +88,6 @@ SIGNATURES = {
     "mc_gn_act_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mc_gn_act_bwd_apply": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _GS, _GS, _vp, _vp]),
-    "mc_gn_act_bwd_apply_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
-                                            _GS, _GS, _vp, _vp, _vp, _vp]),
     "mc_avgpool_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_rect_copy": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _vp]),

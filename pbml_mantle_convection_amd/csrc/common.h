@@ -324,8 +324,3 @@ __device__ __forceinline__ void grad_fetch_add(const mc_grad_src& g, int n, int 
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] += scale * v[j];
 }
-
-// Traversal direction of the next launch (mc_set_direction): 1 = the batch-streaming kernels walk their samples / work items
-// from the LAST to the first, so that a consumer starts on the bytes its producer wrote last (still in the 256 MiB
-// Infinity Cache).  Read by the launchers, passed to the kernels as an argument (captured per launch by a HIP graph).
-extern int mc_g_reverse;

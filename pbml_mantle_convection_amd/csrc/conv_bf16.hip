@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   }
   auto prefetch = [&](int t) {
     const int jitem = t / chunks, ck = t - jitem * chunks;
-    const int wi = g.rev ? items - 1 - (bid + jitem * (int)gridDim.x) : bid + jitem * (int)gridDim.x;
+    const int wi = bid + jitem * (int)gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
     if (ck != chunks - 1) continue;
 
     // ---- epilogue of this work item, straight from the accumulators
-    const int wi = g.rev ? items - 1 - (bid + jitem * (int)gridDim.x) : bid + jitem * (int)gridDim.x;
+    const int wi = bid + jitem * (int)gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
     f32x2 s1[NT][2], s2[NT][2];                                  // per-lane (sum, sum of squares) of channel pairs
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
   int pact[2] = {-1, -1};
   unsigned okm = 0xffffffffu;
   auto prefetch = [&](int wi_fwd) __attribute__((always_inline)) {
-    const int wi = g.rev ? g.N * tiles - 1 - wi_fwd : wi_fwd;
+    const int wi = wi_fwd;
     const int n = wi / tiles, tile = wi - n * tiles;
     const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * WTW;
     const bool interior = (ty0 - g.pad >= 0) && (ty0 - g.pad + TIH <= g.H) && (tx0 - g.pad >= 0) && (tx0 - g.pad + TIW <= g.W);
@@ -958,8 +958,7 @@ const char* mc_bf16_kernel_name(const ConvGeom& g) {
 
 int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
                    void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s) {
-  ConvGeom g = g_in;
-  g.rev = mc_g_reverse;
+  const ConvGeom& g = g_in;
   Bf16Cfg c = cfg_for(g.Cout);
   int nt_total = (g.Cout + 15) / 16;
   int groups = (nt_total + c.nt - 1) / c.nt;
@@ -993,8 +992,7 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
 
 int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* dy, void* part, const ConvFuse& fz,
                   int fuse, hipStream_t s) {
-  ConvGeom g = g_in;
-  g.rev = mc_g_reverse;
+  const ConvGeom& g = g_in;
   const int tiles_x = (g.Wo + WTW - 1) / WTW, tiles_y = (g.Ho + WTH - 1) / WTH;
   const int tiles = tiles_x * tiles_y;
   const int ntiles = (g.Cout + 15) / 16;

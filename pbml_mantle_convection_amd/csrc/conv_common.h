@@ -11,7 +11,6 @@ struct ConvGeom {
   int split8;               // dgrad: first split8 output blocks go to y0 (0 = no split)
   int tiles_x, tiles_y, tiles;
   int wgrad_G;              // number of partial slabs of the filter-gradient reduction
-  int rev;                  // walk the work items from the last to the first (mc_set_direction)
   int sym_h, U;             // mirrored filters / unique filters
   int dtype;
   int out_f32;
@@ -108,7 +107,6 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   if (G > cap) G = cap;
   if (G > work) G = work;
   g.wgrad_G = (int)G;
-  g.rev = 0;
   return MC_OK;
 }
 

@@ -95,26 +95,31 @@ __global__ void k_zero_f32(float* __restrict__ p, int n) {
   if (i < n) p[i] = 0.f;
 }
 
-__global__ void k_sum_hw(const float* __restrict__ x, int hw, float scale, float* __restrict__ out) {
-  // grid (chunks, nc): each block reduces a slice of one plane and adds it to out[nc] (zeroed by the caller)
-  const float* p = x + (size_t)blockIdx.y * hw;
+__global__ __launch_bounds__(1024) void k_sum_hw(const float* __restrict__ x, int hw, float scale, float* __restrict__ out) {
+  // one block per plane (deterministic: fixed per-thread strides, ordered combine; round 1 added 64 block partials per
+  // plane with float atomics)
+  const float* p = x + (size_t)blockIdx.x * hw;
   float s = 0.f;
   if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {        // planes are 16-byte aligned: 4 pixels per load
     const float4* p4 = reinterpret_cast<const float4*>(p);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw / 4; i += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < hw / 4; i += blockDim.x) {
       const float4 v = p4[i];
       s += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
     s = (s + s1) + (s2 + s3);
   } else {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) s += p[i];
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
   }
   s = wave_sum(s);
-  __shared__ float red[4];
+  __shared__ float red[16];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out + blockIdx.y, ((red[0] + red[1]) + (red[2] + red[3])) * scale);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
+    out[blockIdx.x] = t * scale;
+  }
 }
 
 // =================================================================================================
@@ -227,7 +232,7 @@ static int gn_fwd_vpt() { static int v = env_int("MC_GN_FWD_VPT", 8); return v; 
 static int gn_apply_rows(int h, int w) { static int v = env_int("MC_GN_ROWS", 0); if (v > 0) return v; return w > 256 ? GN_ROWS : (w > 32 ? 16 : 32); }
 
 struct GnArgs {
-  int N, C, C8, H, W, groups, cpg, post, act, rev;
+  int N, C, C8, H, W, groups, cpg, post, act;
   const float* stats;
   const float* gamma;
   const float* beta;
@@ -255,7 +260,7 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
   // one thread per POOLxPOOL pixel block of one channel block
   const int Hb = (a.H + POOL - 1) / POOL, Wb = (a.W + POOL - 1) / POOL;
   const int Hp = a.H / POOL, Wp = a.W / POOL;
-  const int n = a.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y;
+  const int n = (int)blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8];
   gn_coef(a, n, cb, sc, sh);
   const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
@@ -326,7 +331,7 @@ static int gkind_of(const mc_grad_src& g0, const mc_grad_src& g1) {
 template <typename T, int GK>
 __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
                                                        mc_grad_src g1, float* __restrict__ part, int CP) {
-  const int n = a.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int n = (int)blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   float sc[8], sh[8], mean[8], rstd[8];
   gn_coef(a, n, cb, sc, sh);
 #pragma unroll
@@ -390,89 +395,101 @@ __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __r
   }
 }
 
-// phase 2: one block per (group g, sample n): m12[n][g] = (sum_c gamma_c s1, sum_c gamma_c s2)/M;
-// dgamma[c] += s2[n][c]; dbeta[c] += s1[n][c]  (N float atomics per channel)
-__global__ void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blocks, int C, int CP, int groups,
-                                  int hw, const float* __restrict__ gamma, float* __restrict__ m12,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int g = blockIdx.x, n = blockIdx.y, cpg = C / groups;
-  double m1 = 0.0, m2 = 0.0;
-  if (pow2_le64(cpg)) {
-    double a1, a2;
-    group_channel_sums(part, (size_t)n * blocks, blocks, CP, g * cpg, cpg, a1, a2);
-    const int lane = threadIdx.x & 63, c = g * cpg + (lane % cpg);
-    if (lane < cpg) {
-      if (dgamma) atomicAdd(dgamma + c, (float)a2);
-      if (dbeta) atomicAdd(dbeta + c, (float)a1);
+// phase 2: one block per group g: m12[n][g] = (sum_c gamma_c s1, sum_c gamma_c s2) / M for every sample, and
+// dgamma[c] += sum_n s2[n][c], dbeta[c] += sum_n s1[n][c].  DETERMINISTIC: the 16 waves of the block take the samples
+// round-robin, park their per-(sample, channel) sums in LDS, and one thread per (channel, kind) adds them in sample order
+// (round 1 used N float atomics per channel: the training step was not reproducible from run to run).
+constexpr int GNF_CHUNK = 256;          // samples per LDS round
+__global__ __launch_bounds__(1024) void k_gn_bwd_finalize(const float* __restrict__ part, int N, int blocks, int C, int CP,
+                                                          int groups, int hw, const float* __restrict__ gamma,
+                                                          float* __restrict__ m12, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  const int g = blockIdx.x, cpg = C / groups;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  __shared__ float sm[GNF_CHUNK][16];                      // [sample][2 * channel-in-group + (0: s1, 1: s2)], cpg <= 8
+  const double M = (double)cpg * (double)hw;
+  if (pow2_le64(cpg) && cpg <= 8) {
+    float tot = 0.f;                                        // thread t < 2 cpg: running sum of value t over the samples
+    for (int n0 = 0; n0 < N; n0 += GNF_CHUNK) {
+      const int nn = min(GNF_CHUNK, N - n0);
+      for (int k = wave; k < nn; k += nwaves) {
+        const int n = n0 + k;
+        double a1, a2;
+        group_channel_sums(part, (size_t)n * blocks, blocks, CP, g * cpg, cpg, a1, a2);
+        const int c = g * cpg + (lane % cpg);
+        if (lane < cpg) { sm[k][2 * lane] = (float)a1; sm[k][2 * lane + 1] = (float)a2; }
+        const float ga = gamma ? gamma[c] : 1.f;
+        double m1 = ga * a1, m2 = ga * a2;
+        for (int o = 1; o < cpg; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        if (lane == 0 && m12) {
+          m12[((size_t)n * groups + g) * 2 + 0] = (float)(m1 / M);
+          m12[((size_t)n * groups + g) * 2 + 1] = (float)(m2 / M);
+        }
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < 2 * cpg)
+        for (int k = 0; k < nn; ++k) tot += sm[k][threadIdx.x];
+      __syncthreads();
     }
-    const float ga = gamma ? gamma[c] : 1.f;
-    m1 = ga * a1; m2 = ga * a2;
-    for (int o = 1; o < cpg; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
-  } else {
+    if ((int)threadIdx.x < 2 * cpg) {
+      const int c = g * cpg + (threadIdx.x >> 1);
+      if (threadIdx.x & 1) { if (dgamma) dgamma[c] += tot; }
+      else if (dbeta) dbeta[c] += tot;
+    }
+    return;
+  }
+  // general group width: one wave walks the samples and the channels in order
+  if (wave != 0) return;
   for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
-      const float* p = part + (((size_t)n * blocks + t) * CP + c) * 2;
-      a1 += (double)p[0];
-      a2 += (double)p[1];
+    float tg = 0.f, tb = 0.f;
+    for (int n = 0; n < N; ++n) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int t = lane; t < blocks; t += 64) {
+        const float* p = part + (((size_t)n * blocks + t) * CP + c) * 2;
+        a1 += (double)p[0];
+        a2 += (double)p[1];
+      }
+      a1 = wave_sum_d(a1);
+      a2 = wave_sum_d(a2);
+      tb += (float)a1;
+      tg += (float)a2;
     }
-    a1 = wave_sum_d(a1);
-    a2 = wave_sum_d(a2);
-    float ga = gamma ? gamma[c] : 1.f;
-    m1 += ga * a1;
-    m2 += ga * a2;
-    if (threadIdx.x == 0) {
-      if (dgamma) atomicAdd(dgamma + c, (float)a2);
-      if (dbeta) atomicAdd(dbeta + c, (float)a1);
+    if (lane == 0) {
+      if (dgamma) dgamma[c] += tg;
+      if (dbeta) dbeta[c] += tb;
     }
   }
-  }
-  if (threadIdx.x == 0 && m12) {
-    double M = (double)cpg * (double)hw;
-    m12[((size_t)n * groups + g) * 2 + 0] = (float)(m1 / M);
-    m12[((size_t)n * groups + g) * 2 + 1] = (float)(m2 / M);
+  if (m12) {
+    for (int n = 0; n < N; ++n) {
+      double m1 = 0.0, m2 = 0.0;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int t = lane; t < blocks; t += 64) {
+          const float* p = part + (((size_t)n * blocks + t) * CP + c) * 2;
+          a1 += (double)p[0];
+          a2 += (double)p[1];
+        }
+        a1 = wave_sum_d(a1);
+        a2 = wave_sum_d(a2);
+        const float ga = gamma ? gamma[c] : 1.f;
+        m1 += ga * a1;
+        m2 += ga * a2;
+      }
+      if (lane == 0) {
+        m12[((size_t)n * groups + g) * 2 + 0] = (float)(m1 / M);
+        m12[((size_t)n * groups + g) * 2 + 1] = (float)(m2 / M);
+      }
+    }
   }
 }
 
 // phase 3: dy = rstd (dz gamma - m1 - yhat m2)   (GN)   |   dy = da act'(y)   (act only)
-template <typename T, bool FUSED, int GK = 0>
+template <typename T, int GK = 0>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restrict__ y, const float* __restrict__ m12,
-                                                      mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy,
-                                                      const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta, int rows_pb) {
-  const int n = a.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y;
+                                                      mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy, int rows_pb) {
+  const int n = (int)blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8], mean[8], rstd[8], ga[8], m1[8], m2[8];
   gn_coef(a, n, cb, sc, sh);
-  __shared__ float fsum[4][16];
-  if (FUSED) {
-    // phase 2 inside phase 3: sum the phase-1 partials of this channel block (nblk x 8 channels x 2)
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    const int CP = a.C8 * 8;
-    for (int t = threadIdx.x; t < nblk; t += blockDim.x) {
-      const float4* p = reinterpret_cast<const float4*>(part + (((size_t)n * nblk + t) * CP + cb * 8) * 2);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = p[q];
-        acc[q * 4 + 0] += v.x; acc[q * 4 + 1] += v.y; acc[q * 4 + 2] += v.z; acc[q * 4 + 3] += v.w;
-      }
-    }
-    {
-      int idx;
-      float r = wave_sum16(acc, threadIdx.x & 63, idx);
-      if ((threadIdx.x & 3) == 0) fsum[threadIdx.x >> 6][idx] = r;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < 16) {
-      int c = cb * 8 + (threadIdx.x >> 1);
-      if (c < a.C) {
-        float r = (fsum[0][threadIdx.x] + fsum[1][threadIdx.x]) + (fsum[2][threadIdx.x] + fsum[3][threadIdx.x]);
-        if (threadIdx.x & 1) { if (dgamma) atomicAdd(dgamma + c, r); }      // sum dz * yhat
-        else if (dbeta) atomicAdd(dbeta + c, r);                             // sum dz
-      }
-    }
-  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int c = cb * 8 + j;
@@ -483,22 +500,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
         mean[j] = a.stats[((size_t)n * a.groups + g) * 2];
         rstd[j] = a.stats[((size_t)n * a.groups + g) * 2 + 1];
         ga[j] = a.gamma[c];
-        if (FUSED) {
-          // group sums over the cpg channels of this group (all inside this channel block: cpg divides 8)
-          const float M = (float)a.cpg * (float)(a.H * a.W);
-          float t1 = 0.f, t2 = 0.f;
-          for (int cc = g * a.cpg; cc < (g + 1) * a.cpg; ++cc) {
-            int jj = cc - cb * 8;
-            float gg = a.gamma[cc];
-            t1 += gg * ((fsum[0][jj * 2] + fsum[1][jj * 2]) + (fsum[2][jj * 2] + fsum[3][jj * 2]));
-            t2 += gg * ((fsum[0][jj * 2 + 1] + fsum[1][jj * 2 + 1]) + (fsum[2][jj * 2 + 1] + fsum[3][jj * 2 + 1]));
-          }
-          m1[j] = t1 / M;
-          m2[j] = t2 / M;
-        } else {
-          m1[j] = m12[((size_t)n * a.groups + g) * 2];
-          m2[j] = m12[((size_t)n * a.groups + g) * 2 + 1];
-        }
+        m1[j] = m12[((size_t)n * a.groups + g) * 2];
+        m2[j] = m12[((size_t)n * a.groups + g) * 2 + 1];
       } else { ga[j] = 1.f; rstd[j] = 1.f; }
     }
   }
@@ -651,8 +654,8 @@ __global__ __launch_bounds__(256) void k_fold_padded_dz(T* __restrict__ buf, int
 template <typename T, int GK>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply_dz(mc_grad_src gs, const T* __restrict__ y, int C, int C8, int H, int W,
                                                          int groups, const float* __restrict__ coef4,
-                                                         const float* __restrict__ m12, T* __restrict__ dy, int rows_pb, int rev) {
-  const int n = rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, cb = blockIdx.y;
+                                                         const float* __restrict__ m12, T* __restrict__ dy, int rows_pb) {
+  const int n = blockIdx.z, cb = blockIdx.y;
   float cA[8], cB[8], cC[8], me[8];
   const int cpg = C / groups;
 #pragma unroll
@@ -1167,11 +1170,9 @@ inline dim3 grid3(int per_plane, int c8, int n, int block = 256, int capx = 64) 
 // ====================================================================================================
 // C ABI
 // ====================================================================================================
-int mc_g_reverse = 0;
 
 extern "C" {
 
-int mc_set_direction(int32_t reverse) { mc_g_reverse = reverse ? 1 : 0; return MC_OK; }
 
 
 int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
@@ -1213,10 +1214,7 @@ int mc_pack_grad_nchw(const float* g, int32_t n, int32_t c, int32_t h, int32_t w
 
 int mc_sum_hw(const float* x, int32_t nc, int32_t hw, float scale, float* out, void* stream) {
   if (!x || !out || nc <= 0 || hw <= 0) return MC_EINVAL;
-  hipLaunchKernelGGL(k_zero_f32, dim3(cdiv(nc, 256)), dim3(256), 0, (hipStream_t)stream, out, nc);
-  int chunks = cdiv(hw, 256 * 16);
-  if (chunks > 64) chunks = 64;
-  hipLaunchKernelGGL(k_sum_hw, dim3(chunks, nc), dim3(256), 0, (hipStream_t)stream, x, hw, scale, out);
+  hipLaunchKernelGGL(k_sum_hw, dim3(nc), dim3(1024), 0, (hipStream_t)stream, x, hw, scale, out);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -1273,7 +1271,6 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
                   const float* gamma, const float* beta, int32_t post, int32_t act, int32_t pool, int32_t dtype,
                   void* a_out, void* pooled, void* stream) {
   GnArgs a;
-  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (!y || (!a_out && pool == 1) || (pool > 1 && !pooled)) return MC_EINVAL;
@@ -1334,7 +1331,6 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
                          const float* gamma, const float* beta, int32_t post, int32_t act, int32_t dtype,
                          const mc_grad_src* g0, const mc_grad_src* g1, float* partials, void* stream) {
   GnArgs a;
-  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (post != MC_POST_GN_ACT || !y || !partials || !g0) return MC_EINVAL;
@@ -1355,7 +1351,7 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
 int mc_gn_act_bwd_finalize(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups, int32_t hw,
                            const float* gamma, float* m12, float* dgamma, float* dbeta, void* stream) {
   if (!partials || n <= 0 || blocks <= 0 || c <= 0 || groups <= 0 || c % groups || hw <= 0) return MC_EINVAL;
-  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(groups, n), dim3(64), 0, (hipStream_t)stream, partials, n, blocks, c,
+  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(groups), dim3(1024), 0, (hipStream_t)stream, partials, n, blocks, c,
                      ((c + 7) / 8) * 8, groups, hw, gamma, m12, dgamma, dbeta);
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1365,7 +1361,6 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
                         const float* m12, const float* gamma, const float* beta, int32_t post, int32_t act,
                         int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream) {
   GnArgs a;
-  a.rev = mc_g_reverse;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (!y || !dy || !g0 || (post == MC_POST_GN_ACT && !m12)) return MC_EINVAL;
@@ -1375,7 +1370,7 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   dim3 g(cdiv(h, rows), a.C8, n);
   hipStream_t s = (hipStream_t)stream;
   const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
-#define APP(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply<T, false, GK>), g, dim3(256), 0, s, a, (const T*)y, m12, s0, s1, (T*)dy, nullptr, 0, nullptr, nullptr, rows)
+#define APP(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply<T, GK>), g, dim3(256), 0, s, a, (const T*)y, m12, s0, s1, (T*)dy, rows)
   if (dtype == MC_F32) APP(float, 0);
   else if (dtype == MC_BF16) {
     switch (gkind_of(s0, s1)) { case 1: APP(bf16_t, 1); break; case 2: APP(bf16_t, 2); break; case 3: APP(bf16_t, 3); break; default: APP(bf16_t, 0); }
@@ -1445,32 +1440,11 @@ int mc_gn_bwd_apply_dz(const mc_grad_src* dz, const void* y, int32_t n, int32_t 
   dim3 g(cdiv(h, rows), C8, n);
   hipStream_t s = (hipStream_t)stream;
   const int gr = groups > 0 ? groups : 1;
-#define APZ(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply_dz<T, GK>), g, dim3(256), 0, s, *dz, (const T*)y, c, C8, h, w, gr, coef, m12, (T*)dy, rows, mc_g_reverse)
+#define APZ(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply_dz<T, GK>), g, dim3(256), 0, s, *dz, (const T*)y, c, C8, h, w, gr, coef, m12, (T*)dy, rows)
   if (dtype == MC_F32) { if (dz->kind == MC_GSRC_PADFOLD) APZ(float, MC_GSRC_PADFOLD); else APZ(float, MC_GSRC_PLAIN); }
   else if (dtype == MC_BF16) { if (dz->kind == MC_GSRC_PADFOLD) APZ(bf16_t, MC_GSRC_PADFOLD); else APZ(bf16_t, MC_GSRC_PLAIN); }
   else return MC_EUNSUPPORTED;
 #undef APZ
-  MC_CHECK_LAUNCH();
-  return MC_OK;
-}
-
-int mc_gn_act_bwd_apply_fused(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
-                              const float* partials, int32_t blocks, const float* gamma, const float* beta, int32_t act,
-                              int32_t dtype, const mc_grad_src* g0, const mc_grad_src* g1, float* dgamma, float* dbeta,
-                              void* dy, void* stream) {
-  GnArgs a;
-  a.rev = mc_g_reverse;
-  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, MC_POST_GN_ACT, act);
-  if (rc) return rc;
-  if (!y || !dy || !g0 || !partials || blocks <= 0) return MC_EINVAL;
-  if (a.cpg > 8 || (8 % a.cpg) != 0) return MC_EUNSUPPORTED;   // a group must not straddle 8-channel blocks
-  if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
-  const int rows = gn_apply_rows(h, w);
-  dim3 g(cdiv(h, rows), a.C8, n);
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL((k_gn_bwd_apply<float, true>), g, dim3(256), 0, s, a, (const float*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (float*)dy, partials, blocks, dgamma, dbeta, rows);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, true>), g, dim3(256), 0, s, a, (const bf16_t*)y, nullptr, gsrc_or_none(g0), gsrc_or_none(g1), (bf16_t*)dy, partials, blocks, dgamma, dbeta, rows);
-  else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

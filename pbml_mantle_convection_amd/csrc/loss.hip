@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void k_loss(LossGeom g, const float* __restric
   // the Unet branch keeps the plain one (:262-266)
   const bool p_scaled = !hasT && g.d.loss_scale && g.d.p_pred;
   const float sp = p_scaled ? fminf(fmaxf(1.0f / (mm[(n * 3 + 2) * 2 + 1] - mm[(n * 3 + 2) * 2 + 0]), 1.0f), 10.0f) : 1.f;
+  // (126 = the reference's literal factor of the derivative loss, multigpu.py:163-166; mc_loss_desc.inv_h belongs to the
+  // momentum residual only)
   const float cdu = 126.0f / (k * (float)g.d.n * (float)(H - 2) * (float)W);
   const float cdv = 126.0f / (k * (float)g.d.n * (float)H * (float)(W - 2));
   // per-thread partial sums in f32 (a thread adds <= a few dozen pixels: relative rounding < 1e-5 of ITS share; the

@@ -361,15 +361,9 @@ class Engine:
         self.mc_dtype, self.t_dtype = DTYPES[precision]
         self.shape = None
         self._tables = {}
-        self.fused_gn_bwd = os.environ.get("MANTLE_FUSED_GN_BWD", "0") != "0"   # A/B on MI355X: the fused form is 0.45 ms/step slower (131 VGPRs)
         # filter-gradient kernels on a second stream: 0 = never, 1 = every layer, 2 = only layers of <= 128 x 128 pixels
         # (their launches are latency-bound and leave most of the chip idle)
         self.wfin_per_layer = os.environ.get("MANTLE_WFIN_PER_LAYER", "1") != "0"   # A/B on MI355X: -0.14 ms/step (the combine leaves the tail of the step)
-        # traversal direction of the batch-streaming kernels (mc_set_direction): 0 = every kernel walks the batch first to
-        # last; 1 = every kernel of the dependent chain runs opposite to its predecessor, so it starts on the bytes written
-        # last (Infinity Cache); 2 = only the GroupNorm kernels run reversed
-        self.zigzag = int(os.environ.get("MANTLE_ZIGZAG", "0"))
-        self._dirn = 0
         self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "1"))   # A/B on MI355X: 1 is 0.25 ms/step faster than 0, 2 is no gain
         # bit 0: GroupNorm + activation applied by the consumers on load (conv, filter gradient, bicubic) instead of a
         # stand-alone pass that materialises the activated tensor; bit 1: the GroupNorm-backward reduction fused into the
@@ -382,9 +376,17 @@ class Engine:
         self.fuse_maxpix = int(os.environ.get("MANTLE_FUSE_MAXPIX", str(128 * 128)))
 
     # -------------------------------------------------------------- planning
+    def freeze(self):
+        """Pin the configured shape: a captured HIP graph holds this engine's device pointers, so re-planning for another
+        batch / grid size would leave the graph replaying freed memory.  Further calls with a different shape raise."""
+        self._frozen = True
+
     def configure(self, N: int, H: int, W: int, device):
         if self.shape == (N, H, W, str(device)):
             return
+        if getattr(self, "_frozen", False):
+            raise RuntimeError(f"this engine is pinned to input shape {self.shape[:3]} by a captured HIP graph; got {(N, H, W)} "
+                               "(use a separate module / engine instance, or an un-captured trainer, for another shape)")
         g = self.g
         if H % g.divisor or W % g.divisor:
             raise ValueError(f"input H, W must be divisible by {g.divisor}")
@@ -528,6 +530,8 @@ class Engine:
         self.dY = self.dYs[0]
         self.convs = [e for e in self.plan if e["node"].kind == "conv" and not e["node"].learned]
         self.side = torch.cuda.Stream(device=device)
+        # events of the two-stream backward, created once (none is created inside a graph capture)
+        self._events = [torch.cuda.Event() for _ in range(2 * len(self.plan) + 2)]
         last = self.plan[-1]
         assert last["node"].kind == "conv", "graph must end in a conv node"
         self.final_plain = last["node"].post == L.POST_NONE
@@ -642,23 +646,10 @@ class Engine:
         return self._tables[key]
 
     # -------------------------------------------------------------- forward
-    def _direction(self, kind: str):
-        """Set the traversal direction for the next launch of the dependent chain (kind: 'conv' | 'gn_rev' | 'gn_fwd' | 'keep' |
-        'reset')."""
-        if not self.zigzag:
-            return
-        if kind == "reset":
-            self._dirn = 0
-        elif self.zigzag == 1:
-            if kind != "keep":
-                self._dirn ^= 1
-        else:
-            self._dirn = 1 if kind == "gn_rev" else 0
-        L.call("mc_set_direction", self._dirn)
-
-    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], chan_scale=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], chan_scale=None, out=None) -> torch.Tensor:
         """x: [N, >= c_in, H, W] f32 device tensor (extra trailing channels are ignored)
-        -> [N, c_out, H', W'] f32.  chan_scale: optional [c_in] f32 per-channel input scale."""
+        -> [N, c_out, H', W'] f32.  chan_scale: optional [c_in] f32 per-channel input scale.  out: optional preallocated
+        result (the fused trainer passes one so that a captured step allocates nothing)."""
         L.require_cuda(x, "network input")
         if x.dtype != torch.float32:
             x = x.float()
@@ -718,7 +709,6 @@ class Engine:
             if node.learned:
                 self._learned_forward(e, srcs[0], params, need_part, st)
             else:
-                self._direction("conv")
                 self._probe_begin()
                 x0, x1, pro = self._sources(srcs)
                 L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None,
@@ -730,13 +720,11 @@ class Engine:
                        L.ptr(gamma), L.ptr(beta), L.ptr(e["stats"]), L.ptr(e.get("coef")), st)
             if o.fused:
                 if node.pool > 1:      # only the pooled tensor is materialised
-                    self._direction("gn_rev")
                     L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
                            L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype, None,
                            L.ptr(T[node.pooled].buf), st)
             elif not final:
                 pooled = T[node.pooled].buf if node.pool > 1 else None
-                self._direction("gn_rev")
                 L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                        L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype,
                        L.ptr(o.buf), L.ptr(pooled), st)
@@ -744,9 +732,11 @@ class Engine:
                 L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, 1, o.H * o.W, 1e-5, None,
                        L.ptr(self.chan_mean), st)
         fo = T[self.plan[-1]["node"].out]
-        out = torch.empty((N, g.c_out, self.out_h, self.out_w), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((N, g.c_out, self.out_h, self.out_w), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (N, g.c_out, self.out_h, self.out_w) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous f32 tensor of the network's output shape")
         out_dt = L.MC_F32 if fo.buf.dtype == torch.float32 else self.mc_dtype
-        self._direction("reset")
         L.call("mc_unpack_nchw", L.ptr(fo.buf), N, fo.C, fo.H, fo.W, g.crop_w, L.ptr(self.chan_mean), out_dt,
                L.ptr(out), st)
         return out
@@ -788,6 +778,7 @@ class Engine:
         self.side.wait_stream(main)
         wg_done = [None, None]
         k = 0
+        evi = 0
         fo = T[self.plan[-1]["node"].out]
         mean = None
         if g.subtract_mean:
@@ -854,7 +845,6 @@ class Engine:
                     L.call("mc_gn_act_bwd_finalize", L.ptr(e["dz_part"]), N, e["dz_blocks"], node.c_out, node.groups,
                            o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
                            L.ptr(grads[node.gn_name + "bias"]), st)
-                self._direction("gn_fwd")
                 L.call("mc_gn_bwd_apply_dz", C.byref(e["dz"]), L.ptr(e["Y"]), N, node.c_out, o.H, o.W, max(node.groups, 1),
                        L.ptr(e["coef"]) if node.post == L.POST_GN_ACT else None, L.ptr(e.get("m12")), self.mc_dtype,
                        L.ptr(dY), st)
@@ -872,27 +862,17 @@ class Engine:
                 g1 = C.byref(gs[1]) if len(gs) > 1 else None
                 gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
                 beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
-                cpg = node.c_out // max(node.groups, 1)
                 if node.post == L.POST_GN_ACT:
-                    self._direction("gn_rev")
                     L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
                            L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
                            L.ptr(e["gpart"]), st)
-                if self.fused_gn_bwd and node.post == L.POST_GN_ACT and cpg <= 8 and 8 % cpg == 0:
-                    # phases 2 + 3 in one launch (the per-(n, group) means are re-derived per workgroup)
-                    L.call("mc_gn_act_bwd_apply_fused", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
-                           L.ptr(e["stats"]), L.ptr(e["gpart"]), e["gblocks"], L.ptr(gamma), L.ptr(beta), act,
-                           self.mc_dtype, g0, g1, L.ptr(grads[node.gn_name + "weight"]),
-                           L.ptr(grads[node.gn_name + "bias"]), L.ptr(dY), st)
-                else:
-                    if node.post == L.POST_GN_ACT:
-                        L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
-                               o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
-                               L.ptr(grads[node.gn_name + "bias"]), st)
-                    self._direction("gn_fwd")
-                    L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
-                           L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
-                           self.mc_dtype, g0, g1, L.ptr(dY), st)
+                if node.post == L.POST_GN_ACT:
+                    L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
+                           o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
+                           L.ptr(grads[node.gn_name + "bias"]), st)
+                L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                       L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
+                       self.mc_dtype, g0, g1, L.ptr(dY), st)
             if node.learned:
                 self._learned_backward(e, srcs[0], dY, params, grads, st)
                 k += 1
@@ -901,10 +881,10 @@ class Engine:
             side = self.side if (self.overlap_wgrad == 1 or (self.overlap_wgrad == 2 and o.H * o.W <= 128 * 128)) else main
             wg_done[k & 1] = None
             if side is not main:
-                ev = torch.cuda.Event()
+                ev = self._events[evi]
+                evi += 1
                 ev.record(main)                           # dY of this layer is complete
                 side.wait_event(ev)
-            self._direction("conv")                    # the filter and the input gradient both start on the dY written last
             with torch.cuda.stream(side):
                 ss = L.stream()
                 L.call("mc_conv2d_wgrad_fused", C.byref(d), x0, x1, pro, L.ptr(dY), L.ptr(e["wpart"]), ss)
@@ -916,12 +896,12 @@ class Engine:
                 else:
                     e["_wfin_done"] = False
                 if side is not main:
-                    wg_done[k & 1] = torch.cuda.Event()
+                    wg_done[k & 1] = self._events[evi]
+                    evi += 1
                     wg_done[k & 1].record(side)
             k += 1
             if e["need_dgrad"]:
                 dxp = e["dxp"]
-                self._direction("keep")
                 pe = e.get("epi")
                 if pe is not None:
                     # the source's GroupNorm-backward reduction rides in this launch: dz and its partial sums instead of dA
@@ -947,7 +927,6 @@ class Engine:
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(self.side)
-        self._direction("reset")
         # one launch combines every layer's partial slabs, folds mirrored filters and accumulates into the gradients
         todo = [e for e in self.convs if not e.get("_wfin_done")]
         n = len(todo)

@@ -37,9 +37,15 @@ class StokesLoss:
         self._shape = None
 
     # ------------------------------------------------------------------
+    def freeze(self):
+        """Pin the buffers: a captured HIP graph holds their device pointers (see Engine.freeze)."""
+        self._frozen = True
+
     def _alloc(self, N, Cc, H, W, dev):
         if self._shape == (N, Cc, H, W, str(dev)):
             return
+        if getattr(self, "_frozen", False):
+            raise RuntimeError(f"this loss object is pinned to shape {self._shape[:4]} by a captured HIP graph; got {(N, Cc, H, W)}")
         f32 = dict(dtype=torch.float32, device=dev)
         self.sums = torch.zeros(L.LOSS_SLOTS, dtype=torch.float64, device=dev)
         self.out8 = torch.zeros(8, **f32)
@@ -128,6 +134,8 @@ class StokesLoss:
         if self.lambda_mom != 0.0:
             if yc is None or paras is None or scaler is None:
                 raise ValueError("the momentum term needs yc [H,W], paras [N,3] and scaler [N]")
+            # ONE depth grid for the whole batch (all samples of a data set share the mesh; a loader delivers it per sample):
+            # Trainer checks once, outside the captured step, that the rows are equal (Trainer._check_single_mesh)
             yc = yc.reshape(-1, H, W)[0].float().contiguous()
             paras = paras.reshape(N, 3).float().contiguous()
             scaler = scaler.reshape(N).float().contiguous()

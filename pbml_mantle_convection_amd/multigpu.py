@@ -184,20 +184,41 @@ class Trainer:
         b1, b2 = g.get("betas", (0.9, 0.999))
         return float(b1), float(b2), float(g.get("eps", 1e-8)), float(g.get("weight_decay", 0.0))
 
-    def _fwd_bwd(self, gVTp, uvp, yc, paras, scaler, train=True):
+    def _fwd_bwd(self, gVTp, uvp, yc, paras, scaler, train=True, eng=None, loss=None):
         """pack -> forward -> fused loss fwd+bwd -> backward, all raw kernel launches (graph-capturable)."""
         m = self.model_uvp
-        eng = m.engine()
+        if eng is None:
+            eng, loss = m.engine(), self.loss
         if not self.flat.bound():
             raise RuntimeError("model parameters were re-allocated (e.g. .to()/.double()) after the Trainer "
                                "flattened them")
         params = self.flat.views(self.flat.param)
-        y = eng.forward(gVTp, params, self.chan_scale)
-        out8, gy = self.loss.evaluate(y, uvp, yc, paras, scaler)
+        self._check_single_mesh(yc)
+        key = (tuple(gVTp.shape), str(gVTp.device))
+        if eng is m.engine() and getattr(self, "_ybuf_key", None) != key:   # network output buffer, allocated outside any capture
+            eng.configure(gVTp.shape[0], gVTp.shape[2], gVTp.shape[3], gVTp.device)
+            self._ybuf = torch.empty((gVTp.shape[0], eng.g.c_out, eng.out_h, eng.out_w), dtype=torch.float32, device=gVTp.device)
+            self._ybuf_key = key
+        y = eng.forward(gVTp, params, self.chan_scale, out=self._ybuf if eng is m.engine() else None)
+        out8, gy = loss.evaluate(y, uvp, yc, paras, scaler)
         if train:
             self.flat.grad.zero_()
             eng.backward(gy, params, self.flat.views(self.flat.grad))
         return out8
+
+    def _check_single_mesh(self, yc):
+        """The momentum residual evaluates the viscosity with ONE depth grid yc [H, W] for the whole batch (sample 0's).
+        A batch whose samples carry different grids would silently get wrong residuals: checked once per tensor (one host
+        sync, never inside a captured step)."""
+        if yc is None or self.loss.lambda_mom == 0.0 or yc.dim() < 3 or yc.shape[0] <= 1:
+            return
+        key = (yc.data_ptr(), tuple(yc.shape))
+        if getattr(self, "_mesh_checked", None) == key or torch.cuda.is_current_stream_capturing():
+            return
+        y2 = yc.reshape(yc.shape[0], -1)
+        if not bool((y2 == y2[:1]).all()):
+            raise ValueError("the momentum residual needs one depth grid yc for the whole batch (all samples on the same mesh)")
+        self._mesh_checked = key
 
     def _optim_step(self):
         b1, b2, eps, wd = self._adam_args()
@@ -237,6 +258,10 @@ class Trainer:
                 self._graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_opt):
                     self._optim_step()
+            # the graph holds the engine's and the loss's device pointers: pin their shapes (another batch size through
+            # eval_step / get_loss / model(x) would otherwise re-plan them and the next replay would touch freed memory)
+            self.model_uvp.engine().freeze()
+            self.loss.freeze()
         st = self._static
         # a captured step reads its inputs from fixed buffers; a caller that fills `input_buffers()` in place (a loader
         # writing the next batch straight into them) passes those very tensors and no copy is made
@@ -260,6 +285,16 @@ class Trainer:
         return dict(self._static)
 
     def eval_step(self, gVTp, uvp, yc=None, paras=None, scaler=None):
+        """Forward + loss only.  Once a training graph has been captured its engine is pinned to the captured shape; an
+        evaluation batch of another size runs on an engine / loss pair of its own (same parameters)."""
+        if self._graph is not None and tuple(gVTp.shape) != tuple(self._static["gVTp"].shape):
+            if getattr(self, "_eval_pair", None) is None:
+                import copy
+                from .engine import Engine
+                lo = copy.copy(self.loss)
+                lo._shape, lo._frozen = None, False
+                self._eval_pair = (Engine(self.model_uvp._graph, self.model_uvp.precision), lo)
+            return self._fwd_bwd(gVTp, uvp, yc, paras, scaler, train=False, eng=self._eval_pair[0], loss=self._eval_pair[1])
         return self._fwd_bwd(gVTp, uvp, yc, paras, scaler, train=False)
 
     # ------------------------------------------------------------------ reference loop

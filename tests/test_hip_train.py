@@ -338,8 +338,8 @@ def test_resident_dataset_assembles_batches_on_device():
 
 def test_bf16_training_tracks_fp32_training():
     """Sixty fused Adam steps (lr 5e-4) on one synthetic batch: the loss falls in both modes and the bf16 run (polynomial GELU,
-    bf16 activations and gradients) ends near the fp32 run.  (Loose bounds: the step is not bit-reproducible - float atomics in the
-    GroupNorm parameter gradients - and Adam amplifies that on this tiny problem.)"""
+    bf16 activations and gradients) ends near the fp32 run.  The step is bit-reproducible (test_training_step_is_deterministic),
+    so this comparison has one outcome, not a distribution."""
     from pbml_mantle_convection_amd.datasetio import synthetic_batch
     from pbml_mantle_convection_amd.multigpu import Trainer
     from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
@@ -357,7 +357,69 @@ def test_bf16_training_tracks_fp32_training():
     for prec, h in hist.items():
         assert min(h[-10:]) < 0.9 * h[0], (prec, h[0], h[-10:])
         assert all(np.isfinite(h))
-    # medians of the last ten steps: single steps of this chaotic toy problem jump by 10-20 % from run to run (one run in
-    # eight missed the former 20 % bound on the mean of five)
+    # medians of the last ten steps (single steps of this chaotic toy problem jump by 10-20 %)
     a, b = float(np.median(hist["bf16"][-10:])), float(np.median(hist["fp32"][-10:]))
-    assert abs(a - b) <= 0.35 * b, (a, b)
+    assert abs(a - b) <= 0.20 * b, (a, b)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_training_step_is_deterministic(prec):
+    """Two runs of the same three fused training steps (HIP-graph replay, momentum term on, several tiles / partial slabs per
+    layer) leave bit-identical parameters and Adam moments: every reduction of the step is ordered (filter gradients: slab
+    combine; GroupNorm parameter gradients: per-sample sums added in sample order; no float atomics on the training state)."""
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    batch = [t.to(DEV) for t in synthetic_batch(6, 80, 150, 5, p_pred=True, device="cpu")]
+    gVTp, uvp, scaler, paras, yc = batch
+    res = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        m = Unet(3, 10, 16, 4, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1000], gamma=0.5)
+        tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet", loss_type="mass",
+                     lambda_mom=1e-6, precision=prec, use_graph=True)
+        for _ in range(3):
+            tr.train_step(gVTp, uvp, yc, paras, scaler)
+        torch.cuda.synchronize()
+        res.append((tr.flat.param.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.flat.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_eval_with_another_batch_size_after_capture():
+    """A captured training graph pins the engine's buffers; evaluation on a batch of another size must neither corrupt the next
+    replay nor fail (it runs on an engine of its own), and re-planning the pinned engine raises instead of freeing memory."""
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    b4 = [t.to(DEV) for t in synthetic_batch(4, 48, 70, 5, p_pred=True, device="cpu")]
+    b2 = [t.to(DEV) for t in synthetic_batch(2, 48, 70, 6, p_pred=True, device="cpu")]
+
+    def make():
+        torch.manual_seed(3)
+        m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1000], gamma=0.5)
+        return Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet", loss_type="mass",
+                       precision="fp32", use_graph=True)
+
+    def args(b):
+        g, u, sc, pa, yc = b
+        return g, u, yc, pa, sc
+
+    ref = make()
+    for _ in range(3):
+        ref.train_step(*args(b4))
+    tr = make()
+    tr.train_step(*args(b4))
+    e2 = tr.eval_step(*args(b2)).clone()                     # other batch size, between two replays
+    tr.train_step(*args(b4))
+    e4 = tr.eval_step(*args(b4)).clone()                     # captured size: the pinned engine itself
+    tr.train_step(*args(b4))
+    torch.cuda.synchronize()
+    assert torch.equal(tr.flat.param, ref.flat.param)
+    assert torch.isfinite(e2).all() and torch.isfinite(e4).all()
+    with pytest.raises(RuntimeError, match="pinned"):
+        tr.model_uvp.engine().configure(2, 48, 70, torch.device(DEV))
