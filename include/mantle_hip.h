@@ -117,6 +117,9 @@ const char* mc_strerror(int code);
  * channel on the way in (xc/4, yc/4, dt/roll_forward). */
 int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
                  int32_t pad_mode, const float* chan_scale, int32_t dtype, void* out, void* stream);
+/* bf16, split precision ("mixed" mode): out_hi = bf16(x), out_lo = bf16(x - out_hi), both CB8 as above. */
+int mc_pack_nchw_split(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
+                       int32_t pad_mode, const float* chan_scale, void* out_hi, void* out_lo, void* stream);
 /* CB8 -> NCHW f32, optionally subtracting a per-(n,c) mean and cropping crop_w columns on
  * both sides ((y - mean(y))[..., 3:-3], pytorch_networks_convae.py:2024).  mean may be NULL. */
 int mc_unpack_nchw(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w,
@@ -206,6 +209,13 @@ int mc_gn_finalize_coef(const float* stat_partials, int32_t n, int32_t tiles, in
 int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                   const float* stats_ng2, const float* gamma, const float* beta, int32_t post,
                   int32_t act, int32_t pool, int32_t dtype, void* a, void* pooled, void* stream);
+/* bf16 mode, tail of the network: y is an F32 conv output (mc_conv_desc.out_f32); a = act(GN(y)) is evaluated in f32 and
+ * written as two bf16 tensors a_hi = bf16(a), a_lo = bf16(a - a_hi) which the next conv reads as a two-source concat with
+ * its filter bank repeated (a to ~2^-17).  y_bf16 = bf16(y) is what the backward kernels read.  Keeps the second
+ * differences of the momentum residual (reference multigpu.py:186-199) above the rounding noise. */
+int mc_gn_act_split_fwd(const float* y_f32, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                        const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
+                        void* y_bf16, void* a_hi, void* a_lo, void* stream);
 /* Backward of act(GN(y)) given the gradient sources of a.  Phase 1 reduces
  * (sum dz, sum dz*yhat) per (n,c) into partials [n][blocks][c8*8][2]; phase 2 (finalize)
  * turns them into per-(n,g) means and accumulates dgamma/dbeta (in sample order: deterministic); phase 3 writes dy. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mc_version": (C.c_int, []),
     "mc_strerror": (C.c_char_p, [C.c_int]),
     "mc_pack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "mc_pack_nchw_split": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_unpack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _vp]),
+    "mc_gn_act_split_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_gn_bwd_blocks": (_i32, [_i32, _i32]),
     "mc_gn_act_bwd_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _GS,
                                        _GS, _vp, _vp]),

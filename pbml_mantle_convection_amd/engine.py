@@ -22,8 +22,9 @@ import torch
 
 from . import _lib as L
 
+# "mixed" = bf16 storage and MFMA arithmetic with the full-resolution level carried in split precision (Engine.split0)
 DTYPES = {"fp32": (L.MC_F32, torch.float32), "f32": (L.MC_F32, torch.float32),
-          "bf16": (L.MC_BF16, torch.bfloat16)}
+          "bf16": (L.MC_BF16, torch.bfloat16), "mixed": (L.MC_BF16, torch.bfloat16)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -342,6 +343,7 @@ class _T:            # runtime tensor
     gsrcs: list = field(default_factory=list)   # gradient sources registered during backward
     # "normalise on load": the activated tensor is never materialised; consumers read the producer's raw conv output
     # `raw` and apply act(scale * y + shift) from `coef` ([N, CP, 4] table, None = activation only) while staging
+    lo: Optional[torch.Tensor] = None           # split precision ("mixed"): buf holds bf16(a), lo holds bf16(a - buf)
     fused: bool = False
     raw: Optional[torch.Tensor] = None
     coef: Optional[torch.Tensor] = None
@@ -374,6 +376,12 @@ class Engine:
         # costs more than the streaming pass it replaces (level-0 16->16 forward 117 -> 207 us against a 100 us pass);
         # at the deep levels the kernels are launch-latency bound and every fused pass is a launch saved.
         self.fuse_maxpix = int(os.environ.get("MANTLE_FUSE_MAXPIX", str(128 * 128)))
+        # precision "mixed": every full-resolution tensor of the FORWARD pass (packed input, conv outputs, activations) is
+        # carried to ~16 mantissa bits -- conv outputs in f32, activations as (hi, lo) bf16 pairs that the next conv reads as
+        # two sources with its filters repeated (2 x the MFMA work of those layers; the backward pass is plain bf16).  The
+        # momentum residual takes second differences x 126^2 of the output; with 8-bit storage at the full-resolution level
+        # its value is rounding noise (2.0 x the exact value at 506^2, tests/study_bf16_momentum.py).
+        self.split0 = precision == "mixed"
 
     # -------------------------------------------------------------- planning
     def freeze(self):
@@ -412,6 +420,10 @@ class Engine:
                 cons[i].append(node)
         self.cons = cons
         self.prod = {}                       # tensor id -> plan entry of the conv that produced it (full-resolution output)
+        H0, W0 = T[0].H, T[0].W
+        # split precision needs a plain conv as the consumer of the packed input
+        if self.split0 and all(c.kind == "conv" and not c.learned for c in cons[0]) and cons[0]:
+            T[0].lo = cb8(T[0].C, T[0].H, T[0].W)
         for node in g.nodes:
             if node.kind == "up":
                 s = T[node.src]
@@ -457,9 +469,17 @@ class Engine:
                 continue
             final_f32 = (node.post == L.POST_NONE and node is g.nodes[-1] and self.mc_dtype == L.MC_BF16
                          and node.c_out <= 16)
-            d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
-                           mode, self.mc_dtype, node.sym_h, 0, int(final_f32))
             ho, wo = h + 2 * node.pad - node.k + 1, w + 2 * node.pad - node.k + 1
+            # raw output in f32, activation stored as a (hi, lo) bf16 pair: full-resolution conv + (GN) + act layers
+            split_out = bool(self.split0 and node.post != L.POST_NONE and (ho, wo) == (H0, W0) and node.c_out <= 16
+                             and node.c_out % 8 == 0)
+            # sources read as (hi, lo): [split] or [plain, split] (decoder: upsampled tensor ++ skip connection); any other
+            # combination reads the hi parts only
+            lo_of = [s.lo for s in srcs]
+            hp_in = (lo_of[-1] is not None and all(x is None for x in lo_of[:-1])
+                     and (len(srcs) == 1 or srcs[0].C % 8 == 0))
+            d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
+                           mode, self.mc_dtype, node.sym_h, 0, int(final_f32 or split_out))
             o = T[node.out]
             o.H, o.W = ho, wo
             tiles = L.call("mc_conv_tiles", C.byref(d))
@@ -478,9 +498,23 @@ class Engine:
                      part=torch.empty((N, tiles, coutp, 2), **f32),
                      bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
                      need_dgrad=need_dgrad)
+            if split_out:
+                e["Yf"] = torch.empty((N, (node.c_out + 7) // 8, ho, wo, 8), dtype=torch.float32, device=device)
+                e["lo"] = cb8(node.c_out, ho, wo)
+                o.lo = e["lo"]
+            if hp_in:
+                # forward reads (hi, lo) as a two-source concat with the filters repeated; the gradients use `desc`
+                cs = srcs[-1].C
+                c0 = ((cs + 7) // 8) * 8 if len(srcs) == 1 else srcs[0].C + cs        # channels of source 0 of the launch
+                e["fdesc"] = L.ConvDesc(N, h, w, c0, cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h, 0,
+                                        int(final_f32 or split_out))
+                e["fbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(e["fdesc"]), 0), dtype=torch.uint8, device=device)
+                e["w2"] = None               # [U, c0 + cs, k, k] f32, allocated at the first pack (needs the parameter's shape)
+                if len(srcs) == 2:           # [plain, hi] materialised as one tensor; lo is the second source
+                    e["cat0"] = cb8(c0, h, w)
             fusable = all(c.kind == "up" or (c.kind == "conv" and not c.learned) for c in cons[node.out])
             o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1)
-                           and ho * wo <= self.fuse_maxpix)
+                           and ho * wo <= self.fuse_maxpix and not split_out)
             if o.fused:
                 o.raw, o.act = e["Y"], L.ACTS[g.act]
             elif node.post != L.POST_NONE:
@@ -511,7 +545,7 @@ class Engine:
                 pe = self.prod.get(node.srcs[0])
                 if ((self.fuse & 2) and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
                         and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1
-                        and h * w <= self.fuse_maxpix):
+                        and h * w <= self.fuse_maxpix and not hp_in and "Yf" not in pe):
                     dtiles = L.call("mc_conv_tiles", C.byref(dd))
                     fblocks = L.call("mc_fold_blocks", h, w, node.pad, mode)
                     e["epi"] = pe
@@ -667,8 +701,12 @@ class Engine:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 self._pack_all_banks(params, L.stream())
-        L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
-               L.ptr(T[0].buf), st)
+        if T[0].lo is not None:
+            L.call("mc_pack_nchw_split", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), L.ptr(T[0].buf),
+                   L.ptr(T[0].lo), st)
+        else:
+            L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
+                   L.ptr(T[0].buf), st)
         if self.overlap_wgrad:
             main.wait_stream(self.side)
         else:
@@ -710,15 +748,32 @@ class Engine:
                 self._learned_forward(e, srcs[0], params, need_part, st)
             else:
                 self._probe_begin()
-                x0, x1, pro = self._sources(srcs)
-                L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None,
-                       L.ptr(e["part"]) if need_part else None, None, st)
+                yout = e["Yf"] if "Yf" in e else e["Y"]
+                if "fdesc" in e:       # split-precision input: (hi, lo) of the last source
+                    x0 = srcs[0].buf
+                    if "cat0" in e:
+                        ptrs = (C.c_void_p * 2)(L.ptr(srcs[0].buf), L.ptr(srcs[1].buf))
+                        cs2 = (C.c_int32 * 2)(srcs[0].C, srcs[1].C)
+                        L.call("mc_concat_cb8", ptrs, cs2, 2, N, srcs[0].H, srcs[0].W, self.mc_dtype, L.ptr(e["cat0"]), st)
+                        x0 = e["cat0"]
+                    L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(x0), L.ptr(srcs[-1].lo), None,
+                           L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), None, L.ptr(e["part"]) if need_part else None, None, st)
+                else:
+                    x0, x1, pro = self._sources(srcs)
+                    L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(yout), None,
+                           L.ptr(e["part"]) if need_part else None, None, st)
                 self._probe_end(d, "fwd " + node.name)
             if node.post == L.POST_GN_ACT:
                 # (mean, rstd) per (sample, group) + the (scale, shift, mean, rstd) table consumers normalise on load with
                 L.call("mc_gn_finalize_coef", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
                        L.ptr(gamma), L.ptr(beta), L.ptr(e["stats"]), L.ptr(e.get("coef")), st)
-            if o.fused:
+            if "Yf" in e:
+                L.call("mc_gn_act_split_fwd", L.ptr(e["Yf"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
+                       L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(e["Y"]), L.ptr(o.buf), L.ptr(e["lo"]), st)
+                if node.pool > 1:
+                    L.call("mc_avgpool_fwd", L.ptr(o.buf), N, node.c_out, o.H, o.W, node.pool, self.mc_dtype,
+                           L.ptr(T[node.pooled].buf), st)
+            elif o.fused:
                 if node.pool > 1:      # only the pooled tensor is materialised
                     L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
                            L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype, None,
@@ -943,7 +998,16 @@ class Engine:
         jobs = []
         for e in self.convs:
             w = self._param(params, e["node"].name + "weight")
-            jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))
+            if "fdesc" in e:
+                fd = e["fdesc"]
+                ci, cs = w.shape[1], fd.c_in1            # the last cs input channels are the split source
+                if e["w2"] is None:
+                    e["w2"] = torch.zeros((w.shape[0], fd.c_in0 + cs, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
+                e["w2"][:, :ci].copy_(w)                 # (channels ci .. c_in0 stay zero: padding of a lone 10-channel input)
+                e["w2"][:, fd.c_in0:].copy_(w[:, ci - cs:])
+                jobs.append((fd, L.ptr(e["w2"]), 0, L.ptr(e["fbank"])))
+            else:
+                jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))
             if e["need_dgrad"]:
                 jobs.append((e["desc"], L.ptr(w), 1, L.ptr(e["dbank"])))
         n = len(jobs)
@@ -1007,7 +1071,7 @@ class Engine:
 
     def algorithmic_bytes_per_sample(self, precision=None) -> float:
         """3 s (sum_in + sum_out over the conv layers) + s_io (C_i + 2 C_o) H W."""
-        s = 2 if (precision or self.precision) == "bf16" else 4
+        s = 2 if (precision or self.precision) in ("bf16", "mixed") else 4
         tot = 0
         for e in self.plan:
             if e["node"].kind != "conv":

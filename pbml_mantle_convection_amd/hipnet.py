@@ -60,9 +60,10 @@ class HipNetMixin:
         return self._precision
 
     def set_precision(self, precision: str):
-        """'fp32' (parity gate: f32 storage and arithmetic) or 'bf16' (bf16 storage, f32 accumulate)."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        """'fp32' (parity gate: f32 storage and arithmetic), 'bf16' (bf16 storage, f32 accumulate) or 'mixed' (bf16 with the
+        full-resolution level of the forward pass in split precision: what the momentum residual needs, engine.py)."""
+        if precision not in ("fp32", "bf16", "mixed"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'mixed'")
         self._precision = precision
         return self
 

@@ -55,7 +55,12 @@ def ddp_setup(rank, world_size, master_port, backend: Optional[str] = None):
 def broadcast_flat(flat: torch.Tensor, src: int = 0, group=None):
     """Initial parameter broadcast from rank 0 (what DDP's constructor does, reference :69)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(flat, src=src, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":       # rehearsal transport, see allreduce_flat
+            host = flat.detach().cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat.detach().copy_(host)
+        else:
+            dist.broadcast(flat, src=src, group=group)
 
 
 def allreduce_flat(flat_grad: torch.Tensor, group=None, async_op: bool = False):
@@ -65,7 +70,12 @@ def allreduce_flat(flat_grad: torch.Tensor, group=None, async_op: bool = False):
         return (1, None) if async_op else 1
     world = dist.get_world_size(group)
     work = None
-    if world > 1:
+    if world > 1 and flat_grad.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal transport (several ranks on one GPU): stage through the host; RCCL takes the device buffer directly
+        host = flat_grad.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat_grad.copy_(host)
+    elif world > 1:
         work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return (world, work) if async_op else world
 
@@ -97,6 +107,10 @@ class Trainer:
         self.train_data_init, self.cv_data_init = train_data_init, cv_data_init
         self.optimizer, self.scheduler, self.save_every = optimizer, scheduler, save_every
         self.model_uvp = model_uvp.to(self.device)
+        if precision == "bf16" and lambda_mom != 0.0 and os.environ.get("MANTLE_MIXED", "1") != "0":
+            # second differences x 126^2 of a network whose full-resolution tensors carry 8 mantissa bits are rounding
+            # noise (2 x the exact value at 506^2): the momentum term needs the split-precision forward pass
+            precision = "mixed"
         if precision is not None:
             self.model_uvp.set_precision(precision)
         self.model_AD = None
@@ -254,10 +268,10 @@ class Trainer:
             with torch.cuda.graph(self._graph):
                 self._static_out = self._fwd_bwd(st["gVTp"], st["uvp"], st["yc"], st["paras"], st["scaler"],
                                                  train=True)
-            if self.world == 1:
-                self._graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph_opt):
-                    self._optim_step()
+            # Adam is a graph of its own: for world > 1 the flat-gradient all-reduce runs between the two replays
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self._optim_step()
             # the graph holds the engine's and the loss's device pointers: pin their shapes (another batch size through
             # eval_step / get_loss / model(x) would otherwise re-plan them and the next replay would touch freed memory)
             self.model_uvp.engine().freeze()
@@ -269,11 +283,9 @@ class Trainer:
             if st[k] is not None and v is not None and v.data_ptr() != st[k].data_ptr():
                 st[k].copy_(v.reshape(st[k].shape), non_blocking=True)
         self._graph.replay()
-        if self.world == 1:
-            self._graph_opt.replay()
-        else:
+        if self.world > 1:
             allreduce_flat(self.flat.grad)
-            self._optim_step()
+        self._graph_opt.replay()
         return self._static_out
 
     def input_buffers(self):
@@ -515,7 +527,7 @@ def build_arg_parser():
     p.add_argument("--data_dir", type=str, default="/plp_scr1/agar_sh/data/TPH/")
     p.add_argument("--nn_root", type=str, default="./trained_networks/")
     p.add_argument("--synthetic", type=int, nargs=3, metavar=("N", "H", "W"), default=None)
-    p.add_argument("--precision", type=str, default=None, choices=[None, "fp32", "bf16"])
+    p.add_argument("--precision", type=str, default=None, choices=[None, "fp32", "bf16", "mixed"])
     p.add_argument("--lambda_mom", type=float, default=0.0)
     p.add_argument("--use_graph", type=int, default=0)
     p.add_argument("--epochs", type=int, default=None)

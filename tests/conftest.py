@@ -14,6 +14,10 @@ GOLDEN = os.path.join(HERE, "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # multi-process GPU tests fork their ranks from this server: it is started here, before any test initialises the GPU,
+    # so that no process holding a HIP context ever forks or execs
+    from multiprocessing import forkserver
+    forkserver.ensure_running()
 
 
 @pytest.fixture(scope="session")

@@ -81,6 +81,72 @@ def test_cfg3_training_step_506_fp32_vs_oracle():
     assert close / moved > 0.999, close / moved                     # Adam moves each weight by <= lr = 1e-3
 
 
+def _grad_table(tr, st):
+    """per-tensor relative L2 of the HIP flat gradient against the oracle's autograd gradient, and the whole-buffer figure"""
+    rows, num, den = [], 0.0, 0.0
+    for n, gv in tr.flat.views(tr.flat.grad).items():
+        gr = st.sd[n].grad.double()
+        d = float((gv.detach().cpu().double() - gr).norm())
+        num, den = num + d * d, den + float(gr.norm()) ** 2
+        rows.append((n, d / max(float(gr.norm()), 1e-300), float(gr.norm())))
+    return rows, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("lam", [0.0, 1e-6])
+def test_cfg3_training_step_506_bf16_gradients_vs_oracle(lam):
+    """The benched precision at the benched resolution: one CFG-3 step in bf16 at 506x506, batch 2 -- loss tuple and EVERY
+    parameter gradient against the fp64 CPU oracle (same inputs, same weights).  Bounds are the measured bf16 levels x ~1.5:
+    the gradient of a 27-layer bf16 network is an O(2^-8)-noisy estimate, the per-tensor figure is worst for the first-level
+    GroupNorm offsets whose true gradient nearly cancels over 506^2 pixels."""
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    m = _unet()
+    sd = {k: v.detach().clone().double() for k, v in m.state_dict().items()}
+    gVTp, uvp, scaler, paras, yc = synthetic_batch(2, 506, 506, 13, p_pred=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet", loss_type="mass",
+                 lambda_mom=lam, precision="bf16")
+    out8 = tr.train_step(*(t.to(DEV) for t in (gVTp, uvp, yc, paras, scaler)))
+    st = O.CpuUnetStep(sd, dict(levels=5, repeats=3, act="gelu", r_p="reflect", loss_type="mass", use_symm=True, p_pred=True))
+    mom = dict(lambda_mom=lam, yc=yc.double(), paras=paras.double(), scaler=scaler.double()) if lam else None
+    ref = st.step(gVTp.double(), uvp.double(), momentum=mom)
+    got = out8[:7].tolist()
+    rows, whole = _grad_table(tr, st)
+    worst = max((r for r in rows if r[2] > 1e-8), key=lambda r: r[1])
+    print(f"\nbf16 506^2 B=2 lam={lam}: loss got {got} ref {list(ref)}\nflat gradient rel-L2 {whole:.3e}; worst tensor {worst}")
+    for r in sorted(rows, key=lambda r: -r[1])[:8]:
+        print("   %-28s rel %.3e  |g| %.3e" % r)
+    for i in (1, 2, 3, 4):                                  # u, v, p, T data terms
+        assert abs(got[i] - ref[i]) <= 1e-2 * abs(ref[i]), (i, got, ref)
+    assert abs(got[5] - ref[5]) <= 5e-2 * abs(ref[5]), (got, ref)       # divergence: first differences x 126 of bf16-noisy u, v
+    if lam:
+        # momentum residual (second differences x 126^2): the Trainer runs the split-precision ("mixed") forward pass for
+        # it; what is left is the bf16 noise of the coarser levels (4 % in the fp64 emulation, tests/study_bf16_momentum.py)
+        assert m.precision == "mixed"
+        assert abs(got[6] - ref[6]) <= 8e-2 * abs(ref[6]), (got, ref)
+        assert abs(got[0] - ref[0]) <= 8e-2 * abs(ref[0]), (got, ref)
+    big = [r for r in rows if r[2] > 1e-8]                  # conv.5.bias: the output mean is subtracted, its gradient is 0
+    worst = max(big, key=lambda r: r[1])
+    assert whole <= (0.10 if not lam else 0.25), whole
+    assert worst[1] <= (0.15 if not lam else 0.6), worst
+
+
+def test_cfg5_unet_1024_fp32_field_mae_below_1e5():
+    """CFG-5 resolution through the f32 path: u, v, p, T at 1024x1024, batch 1, within MAE 1e-5 of the fp64 oracle."""
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    m = _unet(seed=3)
+    sd = {k: v.detach().clone().double() for k, v in m.state_dict().items()}
+    x = synthetic_batch(1, 1024, 1024, 14, p_pred=True)[0][:, :10]
+    m = m.to(DEV).set_precision("fp32")
+    outs = m(x.to(DEV))
+    ref = O.unet_forward(sd, x.double(), levels=5, repeats=3, act="gelu", r_p="reflect", loss_type="mass", use_symm=True,
+                         p_pred=True)
+    for name, o, r in zip("uvpT", outs, ref):
+        mae = float((o.detach().double().cpu() - r).abs().mean())
+        assert mae < 1e-5, (name, mae)
+
+
 def test_cfg1_convae_128_batch4_fp32_vs_oracle():
     from pbml_mantle_convection_amd.pytorch_networks_convae import ConvAE
     torch.manual_seed(1)
@@ -115,13 +181,17 @@ def test_cfg5_1024_mixed_precision_runs_and_agrees():
                      loss_type="mass", lambda_mom=1e-6, precision=prec)
         gVTp, uvp, scaler, paras, yc = (t.to(DEV) for t in data)
         out8 = tr.train_step(gVTp, uvp, yc, paras, scaler)
-        losses[prec] = out8[:6].tolist()
+        losses[prec] = out8[:7].tolist()
         assert all(np.isfinite(losses[prec]))
         assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
-    # data / divergence terms agree to bf16 accuracy; the total is NOT compared: it contains the momentum residual, whose
-    # second differences (x 126^2) amplify the bf16 rounding noise of the last hidden layer (documented in DESIGN.md §4)
+    # data terms agree to bf16 accuracy; the momentum residual (second differences x 126^2) through the split-precision
+    # forward pass the Trainer selects for it: within 8 % (bf16 noise of the coarser levels: 5.6 % at 1024^2 in the fp64
+    # emulation, tests/study_bf16_momentum.py; plain bf16 storage reads 2.5 x the fp32 value here)
+    print("\n1024^2 loss tuples", losses)
     for i in (1, 2, 3, 4):
         assert abs(losses["bf16"][i] - losses["fp32"][i]) <= 3e-2 * abs(losses["fp32"][i]), (i, losses)
+    for i in (0, 6):
+        assert abs(losses["bf16"][i] - losses["fp32"][i]) <= 8e-2 * abs(losses["fp32"][i]), (i, losses)
 
 
 def test_mirror_property_full_size():

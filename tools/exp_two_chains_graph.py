@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: two half-batch training chains captured as parallel branches of ONE HIP graph vs one full-batch chain.
 (tools/exp_two_chains.py showed that separate graph launches do not overlap; branches of one graph do.)"""
-import os, sys, time
+import faulthandler, os, sys, time
+faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
