@@ -36,7 +36,8 @@ def parse():
     p.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     p.add_argument("--size", type=int, nargs=2, default=[506, 506], metavar=("H", "W"))
     p.add_argument("--precision", type=str, default=os.environ.get("MANTLE_BENCH_PRECISION", "bf16"),
-                   choices=["bf16", "fp32"])
+                   choices=["bf16", "mixed", "fp32"],
+                   help="bf16 with a momentum term runs as 'mixed' (split-precision full-resolution level, see engine.py)")
     p.add_argument("--lambda-mom", type=float, default=1e-6, help="weight of the Stokes momentum residual (CFG-3)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,17 +70,22 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MANTLE_CPU_THREADS", "16"))))
 
 
+PMC_FILE = "round2_pmc_traffic.json"
+
+
 def pmc_traffic(kernel, B, H, W, precision):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    profiles/round1_pmc_traffic.json, collected on this same workload); None for any other workload."""
-    if (B, H, W, precision) != (32, 506, 506, "bf16"):
-        return None
+    """(HBM bytes per launch of the dominant kernel, commit they were measured at) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 + WRITE_SIZE, profiles/round2_pmc_traffic.json, collected on this same workload by tools/profile_round.sh);
+    (None, None) for any other workload.  The counters cannot be read inside this process: the figure is as old as its commit."""
+    if (B, H, W) != (32, 506, 506) or precision not in ("bf16", "mixed"):
+        return None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"].get(kernel.replace(" ", ""))
-        return None if k is None else k["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+            d = json.load(f)
+        k = d["kernels"].get(kernel.replace(" ", ""))
+        return (None, None) if k is None else (k["hbm_bytes_per_launch"], d.get("commit"))
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(args, H, W):
@@ -137,8 +143,8 @@ def main():
     if n1:
         H, W = 128, 506
         args.no_cpu_baseline = True                      # (the CPU baseline leg is the headline workload's)
-    steps = args.steps if args.steps is not None else (20 if args.precision == "bf16" else 3)
-    warmup = args.warmup if args.warmup is not None else (5 if args.precision == "bf16" else 1)
+    steps = args.steps if args.steps is not None else (20 if args.precision != "fp32" else 3)
+    warmup = args.warmup if args.warmup is not None else (5 if args.precision != "fp32" else 1)
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
     if n1:
@@ -197,7 +203,8 @@ def main():
     torch.cuda.synchronize(dev)
     roof = eng.probe_summary(probe, HBM_PEAK_GBS)
     eng.disable_probe()
-    roof["traffic"] = pmc_traffic(roof["kernel"], B, H, W, args.precision) if roof["kernel"] else None
+    roof["traffic"], roof["traffic_measured_at_commit"] = pmc_traffic(roof["kernel"], B, H, W, args.precision) if roof["kernel"] \
+        else (None, None)
 
     line = None
     if rank == 0:
@@ -207,7 +214,7 @@ def main():
                       f"training samples/sec (2-D {H}x{W} Stokes fields)", "value": sps, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": "f32" if model.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": (f"N1: NewFluidNet (levels 5, c_h 16, k 5, repeats 6, zeros, symmetric) + scaled L1 data loss "
                                     f"+ divergence, {H}x{W}, per-GPU batch {B}, Adam, "
                                     f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}"
@@ -216,6 +223,10 @@ def main():
                                    f"+ divergence + Stokes momentum residual, {H}x{W}, per-GPU batch {B}, Adam, "
                                    f"{'HIP-graph replay' if not args.no_graph else 'eager launches'}"
                                    + (f", r_p={args.r_p}" if args.r_p else ""),
+                       "precision": {"fp32": "fp32 storage and arithmetic", "bf16": "bf16 storage, bf16 MFMA, f32 accumulate",
+                                     "mixed": "bf16 MFMA, f32 accumulate; bf16 storage except the full-resolution level of the "
+                                              "forward pass (f32 conv outputs, activations as bf16 hi+lo pairs): the Trainer's "
+                                              "choice for bf16 with a momentum term"}[model.precision],
                        "global_batch": world * B, "grid": [H, W], "parallelism": f"dp{world}",
                        "loss": float(loss)},
             "roofline": roof,

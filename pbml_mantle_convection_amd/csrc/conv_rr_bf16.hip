@@ -17,6 +17,11 @@
 //              stages ahead into registers, then — "normalise on load" — the producer's GroupNorm affine + activation on
 //              the vector ALU (it co-issues with the other waves' MFMAs), then ds_write into the other LDS buffer.
 // One s_barrier per stage.  A stage = one 16-channel input chunk of one (image, tile) work item; work-groups are persistent.
+// (Tried and dropped, round 2: handing the finished bf16 tile to the loader waves through the consumed window buffer so
+// that the MFMA waves skip their store-issue-bound epilogue -- 1700-2300 of ~5600 cycles per tile.  Level-0 16->16 forward
+// 117 -> 148 us: the ~80 KB a work-group moves per tile take 2000-3900 cycles of vector-memory issue whichever waves issue
+// them -- the layer runs at 5.3 TB/s of HBM + halo traffic -- and the second barrier per tile puts that time on the MFMA
+// waves' critical path instead of beside it.)
 // In the input-gradient form (FUSE == 2) the loader waves — which have no activation to apply to dY — also run the
 // epilogue: the MFMA waves hand their f32 accumulators over through LDS and continue with the next stage, the loaders
 // (holding the producer's raw output y for the tile's pixels in registers) form dz = dA act'(z), the GroupNorm-backward

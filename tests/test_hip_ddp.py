@@ -50,5 +50,5 @@ def test_two_ranks_match_each_other_and_the_single_process_step(prec, tmp_path):
     lr = 1e-3
     d = np.abs(r0["param"].astype(np.float64) - one["param"])
     # Adam's first steps move every weight by ~lr whatever |g| is, so an entry whose gradient is ~0 may differ by up to lr
-    assert (d > 0.1 * lr).mean() <= 2e-3, (d > 0.1 * lr).mean()
+    assert (d > 0.1 * lr).mean() <= (2e-3 if prec == "fp32" else 1e-2), (d > 0.1 * lr).mean()
     assert d.max() <= 2.5 * nsteps * lr

@@ -10,6 +10,13 @@ from pbml_mantle_convection_amd.datasetio import synthetic_batch
 from pbml_mantle_convection_amd.multigpu import Trainer
 from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
 
+if os.environ.get("EXP_FORCE") != "1":
+    sys.exit("exp_two_chains_graph.py: known to die with SIGSEGV inside torch.cuda.CUDAGraph.capture_end() (hipStreamEndCapture /\n"
+             "graph instantiation) as soon as TWO training chains are captured as parallel branches of one graph -- reproduced on\n"
+             "ROCm 7.2 / torch 2.10 after every allocation and event creation was moved out of the captured region, with and without\n"
+             "the engines' side streams and the optimizer.  One chain captured the same way replays fine.  Set EXP_FORCE=1 to run it\n"
+             "anyway (host crash only, no GPU hang).  See DESIGN.md section 10.")
+
 dev = torch.device("cuda:0")
 CFG = bench.CFG
 
@@ -77,6 +84,6 @@ with torch.cuda.graph(graph):
 print("captured", flush=True)
 print("%d chains of B=%d as branches of one graph: %.3f ms" % (nch, 32 // nch, timeit(graph.replay)), flush=True)
 
-# Result on MI355X (ROCm 7.2, torch 2.10): one chain captured this way replays at 12.5 ms; with two chains the process
-# dies with SIGSEGV inside CUDAGraph.capture_end (hipStreamEndCapture / graph instantiation), with or without the
-# engines' own side streams (MANTLE_OVERLAP_WGRAD=0) and with or without the optimizer in the capture.  Not pursued.
+# Result on MI355X (ROCm 7.2, torch 2.10), rounds 1 and 2: one chain captured this way replays at 12.1 ms; with two chains the
+# process dies with SIGSEGV inside CUDAGraph.capture_end (faulthandler: torch/cuda/graphs.py:130), also with
+# MANTLE_OVERLAP_WGRAD=0, without the optimizer, and (round 2) with no allocation or event creation inside the capture.

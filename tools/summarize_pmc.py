@@ -24,8 +24,10 @@ for k in sorted(set(F) | set(W)):
     out[k] = {"launches": max(nf, nw), "fetch_bytes_per_launch": 2.0 * 1024 * f / max(nf, 1),
               "write_bytes_per_launch": 1024.0 * w / max(nw, 1)}
     out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
-json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as is; KiB -> bytes; averages over all launches of the kernel "
-                   "in `python bench.py --steps 2 --warmup 1 --no-graph` (batch 32, 506x506, bf16)", "kernels": out},
+import subprocess
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+json.dump({"commit": commit, "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as is; KiB -> bytes; averages over all launches of the kernel "
+                   "in `python bench.py --steps 2 --warmup 1 --no-graph` (batch 32, 506x506, bf16 / mixed); `commit` = HEAD when the summary was written", "kernels": out},
           open(outj, "w"), indent=1)
 if len(sys.argv) > 4:
     with open(sys.argv[4], "w") as o:
