@@ -82,8 +82,12 @@ def pmc_traffic(kernel, B, H, W, precision):
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
-        k = d["kernels"].get(kernel.replace(" ", ""))
-        return (None, None) if k is None else (k["hbm_bytes_per_launch"], d.get("commit"))
+        # the probe names the kernel family (k_conv_rr_bf16<5>); the counters are per instantiation: launch-weighted mean
+        fam = kernel.replace(" ", "").rstrip(">")
+        ks = [v for n, v in d["kernels"].items() if n == kernel.replace(" ", "") or n.startswith(fam + ",")]
+        if not ks:
+            return None, None
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks), d.get("commit")
     except Exception:
         return None, None
 

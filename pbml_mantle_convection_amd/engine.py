@@ -366,7 +366,11 @@ class Engine:
         # filter-gradient kernels on a second stream: 0 = never, 1 = every layer, 2 = only layers of <= 128 x 128 pixels
         # (their launches are latency-bound and leave most of the chip idle)
         self.wfin_per_layer = os.environ.get("MANTLE_WFIN_PER_LAYER", "1") != "0"   # A/B on MI355X: -0.14 ms/step (the combine leaves the tail of the step)
-        self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "1"))   # A/B on MI355X: 1 is 0.25 ms/step faster than 0, 2 is no gain
+        # A/B on MI355X, round 2 (CFG-3, B = 32): 0 = 12.6 / 11.0 ms (mixed / bf16), 1 = 13.1 / 11.6, 2 = 12.8 / 11.3.  The two
+        # full-chip kernels of a layer only time-slice when they run side by side (each takes twice its stand-alone time),
+        # while every cross-queue dependency of the captured step costs 12-17 us (tools/step_timeline.py): one stream wins.
+        # (Round 1 measured the opposite, -0.25 ms for 1, with the slower filter-gradient kernel of that time.)
+        self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "0"))
         # bit 0: GroupNorm + activation applied by the consumers on load (conv, filter gradient, bicubic) instead of a
         # stand-alone pass that materialises the activated tensor; bit 1: the GroupNorm-backward reduction fused into the
         # epilogue of the input-gradient launch (single-consumer tensors).  0 = the round-1 unfused chain (A/B, tests).
@@ -562,6 +566,15 @@ class Engine:
         # prepares dY of layer L-1 (see backward)
         self.dYs = [torch.empty(max_dy, dtype=self.t_dtype, device=device) for _ in range(2)]
         self.dY = self.dYs[0]
+        # ... or one dY buffer per layer (default): the main chain then never waits for the side stream, the captured step is one
+        # linear chain plus a side chain with fork edges only, and the graph executor keeps the chain on one hardware queue
+        # (with the two alternating buffers the joins spread it over three queues: ~17 us per cross-queue hop, 2-3 per layer)
+        self.dy_per_layer = os.environ.get("MANTLE_DY_PER_LAYER", "1") != "0" and self.overlap_wgrad != 0
+        if self.dy_per_layer:
+            for e in self.plan:
+                if e["node"].kind == "conv":
+                    o = T[e["node"].out]
+                    e["dY"] = torch.empty(N * e["coutp"] * o.H * o.W, dtype=self.t_dtype, device=device)
         self.convs = [e for e in self.plan if e["node"].kind == "conv" and not e["node"].learned]
         self.side = torch.cuda.Stream(device=device)
         # events of the two-stream backward, created once (none is created inside a graph capture)
@@ -840,7 +853,7 @@ class Engine:
             L.call("mc_sum_hw", L.ptr(gout), N * g.c_out, self.out_h * self.out_w, 1.0 / (fo.H * fo.W),
                    L.ptr(self.gmean), st)
             mean = self.gmean
-        gdst = self.dYs[0] if self.final_plain else self.dOut
+        gdst = (self.plan[-1]["dY"] if self.dy_per_layer else self.dYs[0]) if self.final_plain else self.dOut
         L.call("mc_pack_grad_nchw", L.ptr(gout), N, g.c_out, fo.H, fo.W, g.crop_w, L.ptr(mean), self.mc_dtype,
                L.ptr(gdst), st)
         if not self.final_plain:
@@ -889,8 +902,8 @@ class Engine:
             d = e["desc"]
             o = T[node.out]
             srcs = [T[i] for i in node.srcs]
-            dY = self.dYs[k & 1]
-            if wg_done[k & 1] is not None:
+            dY = e["dY"] if self.dy_per_layer else self.dYs[k & 1]
+            if not self.dy_per_layer and wg_done[k & 1] is not None:
                 main.wait_event(wg_done[k & 1])          # the side stream has finished reading this dY buffer
             if node.post != L.POST_NONE and "dz" in e:
                 # dz = dA * act'(z) and its partial sums were produced by the consumer's input-gradient launch
@@ -1046,7 +1059,8 @@ class Engine:
             nbytes = d.n * es * (cin * d.h * d.w + d.c_out * ho * wo)          # algorithmic: read input once, write output once
             flops = 2.0 * d.n * cin * d.c_out * d.k * d.k * ho * wo
             name = L.load().mc_conv_kernel_name(C.byref(d)).decode()
-            self._probe.append((name, label, self._probe_ev, ev, nbytes, flops))
+            shape = f"{label.split()[0]} {cin}->{d.c_out} k{d.k} {d.n}x{d.h}x{d.w}"
+            self._probe.append((name, shape, self._probe_ev, ev, nbytes, flops))
 
     @staticmethod
     def probe_summary(probe, hbm_peak_gbs):
@@ -1063,11 +1077,22 @@ class Engine:
                     "kernel": None, "launches": 0}
         name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
         ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+        # the same kernel serves every level of the network: its launches by layer shape (the five that take the most time)
+        shapes = {}
+        for nm, shape, e0, e1, nbytes, flops in probe:
+            if nm == name:
+                v = shapes.setdefault(shape, dict(ms=0.0, bytes=0.0, n=0))
+                v["ms"] += e0.elapsed_time(e1)
+                v["bytes"] += nbytes
+                v["n"] += 1
+        by_shape = [{"layer": k, "launches": v["n"], "avg_launch_us": 1e3 * v["ms"] / v["n"],
+                     "achieved": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / hbm_peak_gbs}
+                    for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])[:5]]
         return {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s", "frac": ach / hbm_peak_gbs,
                 "traffic": None, "kernel": name, "launches": g["n"], "avg_launch_us": 1e3 * g["ms"] / g["n"],
                 "avg_algorithmic_MB_per_launch": g["bytes"] / g["n"] / 1e6,
                 "tflops": g["flops"] / (g["ms"] * 1e-3) / 1e12,
-                "share_of_conv_time": g["ms"] / sum(v["ms"] for v in groups.values())}
+                "share_of_conv_time": g["ms"] / sum(v["ms"] for v in groups.values()), "by_shape": by_shape}
 
     def algorithmic_bytes_per_sample(self, precision=None) -> float:
         """3 s (sum_in + sum_out over the conv layers) + s_io (C_i + 2 C_o) H W."""
