@@ -98,7 +98,7 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
   const size_t slab = wg_slab_floats(g.CoutP, g.CinP, KK);
   const size_t nW = (size_t)KK * nch * g.U * 16;
   const size_t total = nW + g.Cout;
-  const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = threadIdx.x & 63, w = threadIdx.x >> 6, NWV = (int)blockDim.x >> 6;   // 16 or 4 waves per block
   const size_t i = (size_t)lblock * 64 + e;
   __shared__ float red[WF_WAVES][64];
   float s = 0.f;
@@ -127,15 +127,15 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
       const float* part = g.part;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int G = w;
-      for (; G + 3 * WF_WAVES < g.G; G += 4 * WF_WAVES) {
-        a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + WF_WAVES) * slab + o1];
-        a2 += part[(size_t)(G + 2 * WF_WAVES) * slab + o1]; a3 += part[(size_t)(G + 3 * WF_WAVES) * slab + o1];
+      for (; G + 3 * NWV < g.G; G += 4 * NWV) {
+        a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + NWV) * slab + o1];
+        a2 += part[(size_t)(G + 2 * NWV) * slab + o1]; a3 += part[(size_t)(G + 3 * NWV) * slab + o1];
         if (two) {
-          a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + WF_WAVES) * slab + o2];
-          a2 += part[(size_t)(G + 2 * WF_WAVES) * slab + o2]; a3 += part[(size_t)(G + 3 * WF_WAVES) * slab + o2];
+          a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + NWV) * slab + o2];
+          a2 += part[(size_t)(G + 2 * NWV) * slab + o2]; a3 += part[(size_t)(G + 3 * NWV) * slab + o2];
         }
       }
-      for (; G < g.G; G += WF_WAVES) {
+      for (; G < g.G; G += NWV) {
         a0 += part[(size_t)G * slab + o1];
         if (two) a0 += part[(size_t)G * slab + o2];
       }
@@ -148,8 +148,7 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
   __syncthreads();
   if (w == 0 && dst != -1) {
     float r = 0.f;
-#pragma unroll
-    for (int k = 0; k < WF_WAVES; k += 4) r += (red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e]);
+    for (int k = 0; k < NWV; k += 4) r += (red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e]);
     if (dst >= 0) { if (g.dw) g.dw[dst] += r; }
     else if (g.db) g.db[-2 - dst] += r;
   }
@@ -306,18 +305,30 @@ int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const
 int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* const* partials, float* const* dw,
                                      float* const* db, int32_t n, void* stream) {
   if (!descs || !partials || !dw || !db || n <= 0) return MC_EINVAL;
-  for (int base = 0; base < n; base += WF_MAX) {
+  // two passes: layers with many small slabs (levels 0-1: 768 x 25 KB) want 16 waves per 64 outputs (each sums every 16th
+  // slab: latency-bound otherwise), layers with few large slabs (deep levels: 16 x 1.6 MB) 4 waves (1024-thread blocks with
+  // one or two loads per thread cost 338 us for the whole network; the order of the sums is fixed either way)
+  for (int pass = 0; pass < 2; ++pass) {
     WfTable t;
-    t.n = n - base < WF_MAX ? n - base : WF_MAX;
+    t.n = 0;
     int blocks = 0;
-    for (int k = 0; k < t.n; ++k) {
+    auto flush = [&]() {
+      if (t.n == 0) return;
+      hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(pass == 0 ? 64 * WF_WAVES : 256), 0, (hipStream_t)stream, t);
+      t.n = 0; blocks = 0;
+    };
+    for (int k = 0; k < n; ++k) {
+      WfJob j;
       int b = 0;
-      int rc = wf_fill(&descs[base + k], partials[base + k], dw[base + k], db[base + k], t.j[k], b);
+      int rc = wf_fill(&descs[k], partials[k], dw[k], db[k], j, b);
       if (rc) return rc;
-      t.j[k].first_block = blocks;
+      if ((j.G >= 128) != (pass == 0)) continue;
+      j.first_block = blocks;
+      t.j[t.n++] = j;
       blocks += b;
+      if (t.n == WF_MAX) flush();
     }
-    hipLaunchKernelGGL(k_wgrad_finalize, dim3(blocks), dim3(64 * WF_WAVES), 0, (hipStream_t)stream, t);
+    flush();
     MC_CHECK_LAUNCH();
   }
   return MC_OK;

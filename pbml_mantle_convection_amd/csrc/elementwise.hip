@@ -141,7 +141,16 @@ __device__ __forceinline__ void group_channel_sums(const float* __restrict__ par
                                                    int cpg, double& a1, double& a2) {
   const int lane = threadIdx.x & 63, cl = lane % cpg, per = 64 / cpg;
   a1 = 0.0; a2 = 0.0;
-  for (int t = lane / cpg; t < count; t += per) {
+  int t = lane / cpg;
+  // eight loads in flight (the loop was bound by one load latency per iteration: 30 us for the 1024 slots of a level-0 layer)
+  for (; t + 7 * per < count; t += 8 * per) {
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float2*>(part + ((base_n + t + k * per) * CP + c0 + cl) * 2);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a1 += (double)v[k].x; a2 += (double)v[k].y; }
+  }
+  for (; t < count; t += per) {
     const float2 v = *reinterpret_cast<const float2*>(part + ((base_n + t) * CP + c0 + cl) * 2);
     a1 += (double)v.x;
     a2 += (double)v.y;
