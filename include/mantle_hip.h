@@ -88,6 +88,12 @@ typedef struct {
   const float* coef0; /* source 0 */
   const float* coef1; /* source 1 (second torch.cat operand) */
   int32_t act0, act1; /* MC_ACT_* */
+  /* Source 1 held in two tensors (split-precision decoder conv: [upsampled ++ hi] ++ lo would otherwise need a third
+   * operand): its first c_in1a channels (a multiple of 8) come from x1, the remaining c_in1 - c_in1a from x1b.  NULL / 0:
+   * source 1 is one tensor.  Only the row-reuse kernel family reads it (mc_conv_kernel_name(desc) starts with
+   * "k_conv_rr"); any other launch with x1b set returns MC_EUNSUPPORTED.  Forward launches only. */
+  const void* x1b;
+  int32_t c_in1a;
 } mc_conv_prologue;
 
 /* Input-gradient epilogue: the launch computes dA (gradient w.r.t. the ACTIVATED tensor a = act(GN(y))) on the padded

@@ -31,7 +31,8 @@ class GradSrc(C.Structure):
 
 class ConvPrologue(C.Structure):
     """mc_conv_prologue: GroupNorm affine + activation of the producer, applied by the consumer on load."""
-    _fields_ = [("coef0", C.c_void_p), ("coef1", C.c_void_p), ("act0", C.c_int32), ("act1", C.c_int32)]
+    _fields_ = [("coef0", C.c_void_p), ("coef1", C.c_void_p), ("act0", C.c_int32), ("act1", C.c_int32),
+                ("x1b", C.c_void_p), ("c_in1a", C.c_int32)]
 
 
 class ConvEpilogue(C.Structure):

@@ -242,6 +242,10 @@ static int fill_prologue(const mc_conv_prologue* pro, ConvFuse& fz, int& rc) {
   if (!pro) return 0;
   if (!act_ok(pro->act0) || !act_ok(pro->act1)) { rc = MC_EINVAL; return 0; }
   fz.coef0 = pro->coef0; fz.coef1 = pro->coef1; fz.act0 = pro->act0; fz.act1 = pro->act1;
+  if (pro->x1b) {
+    if (pro->c_in1a <= 0 || (pro->c_in1a % 8) != 0) { rc = MC_EINVAL; return 0; }
+    fz.x1b = pro->x1b; fz.cb1a = pro->c_in1a / 8;
+  }
   return (pro->coef0 || pro->coef1 || pro->act0 != MC_ACT_NONE || pro->act1 != MC_ACT_NONE) ? 1 : 0;
 }
 
@@ -268,6 +272,7 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
     fz.estride = epi->part_stride;
     fuse = 2;
   }
+  if (fz.x1b && (!rr_desc(d) || fz.cb1a >= g.CB1 || epi)) return fz.cb1a >= g.CB1 ? MC_EINVAL : MC_EUNSUPPORTED;
   if (rr_desc(d)) return mc_conv2d_rr(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   if (g.dtype == MC_BF16) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   return mc_conv2d_f32(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
@@ -293,6 +298,7 @@ int mc_conv2d_wgrad_fused(const mc_conv_desc* d, const void* x0, const void* x1,
   ConvFuse fz = conv_fuse_none();
   const int fuse = fill_prologue(pro, fz, rc);
   if (rc) return rc;
+  if (fz.x1b) return MC_EUNSUPPORTED;
   if (g.dtype == MC_BF16) return mc_wgrad_bf16(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
   return mc_wgrad_f32(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
 }

@@ -27,11 +27,13 @@ struct ConvFuse {
   float* epart;                             // [N][tiles][CoutP][2]
   int eact, epad, ezero, ehs, ews;          // ezero: forward padding was zeros (every interior pixel is final)
   int estride;                              // slots per sample of epart
+  const void* x1b; int cb1a;                // source 1 held in two tensors: blocks [0, cb1a) from x1, the rest from x1b
 };
 static inline ConvFuse conv_fuse_none() {
   ConvFuse f;
   f.coef0 = f.coef1 = nullptr; f.act0 = f.act1 = MC_ACT_NONE;
   f.ey = nullptr; f.ecoef = nullptr; f.epart = nullptr; f.eact = MC_ACT_NONE; f.epad = 0; f.ezero = 1; f.ehs = f.ews = 0; f.estride = 0;
+  f.x1b = nullptr; f.cb1a = 0;
   return f;
 }
 

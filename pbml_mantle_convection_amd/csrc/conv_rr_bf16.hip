@@ -130,10 +130,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         const int gcb = ck * 2 + cb;
         const int gcc = min(gcb, g.CBin - 1);
         const bool second = gcc >= g.CB0;
-        const int scb = second ? gcc - g.CB0 : gcc;
-        const int sC8 = second ? g.CB1 : g.CB0;
+        int scb = second ? gcc - g.CB0 : gcc;
+        int sC8 = second ? g.CB1 : g.CB0;
+        const void* sp = second ? (const void*)x1 : (const void*)x0;
+        if (second && fz.x1b) {                              // source 1 in two tensors (mc_conv_prologue.x1b)
+          if (scb >= fz.cb1a) { sp = fz.x1b; scb -= fz.cb1a; sC8 = g.CB1 - fz.cb1a; }
+          else sC8 = fz.cb1a;
+        }
         const size_t plane_bytes = (size_t)g.H * g.W * 16;
-        const char* pbase = reinterpret_cast<const char*>(second ? x1 : x0) + ((size_t)n * sC8 + scb) * plane_bytes;
+        const char* pbase = reinterpret_cast<const char*>(sp) + ((size_t)n * sC8 + scb) * plane_bytes;
         // one descriptor per (image, channel-block plane): out-of-range offsets return zeros = zero padding / missing block
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, gcb < g.CBin ? (int)plane_bytes : 0, 0x00020000);
 #pragma unroll

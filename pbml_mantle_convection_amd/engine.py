@@ -514,8 +514,17 @@ class Engine:
                                         int(final_f32 or split_out))
                 e["fbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(e["fdesc"]), 0), dtype=torch.uint8, device=device)
                 e["w2"] = None               # [U, c0 + cs, k, k] f32, allocated at the first pack (needs the parameter's shape)
-                if len(srcs) == 2:           # [plain, hi] materialised as one tensor; lo is the second source
-                    e["cat0"] = cb8(c0, h, w)
+                if len(srcs) == 2:
+                    # [plain ++ hi] ++ lo: the row-reuse kernel takes source 1 in two tensors (x1 = hi, x1b = lo; bank channel
+                    # order plain, hi, lo); any other kernel family gets [plain ++ hi] materialised as one tensor
+                    fd3 = L.ConvDesc(N, h, w, srcs[0].C, 2 * cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h,
+                                     0, int(final_f32 or split_out))
+                    # (A/B on MI355X: -0.2 ms per step against the materialised concat; MANTLE_X1B=0 selects the latter)
+                    if (os.environ.get("MANTLE_X1B", "1") != "0"
+                            and L.load().mc_conv_kernel_name(C.byref(fd3)).decode().startswith("k_conv_rr")):
+                        e["fdesc"], e["x1b"] = fd3, True
+                    else:
+                        e["cat0"] = cb8(c0, h, w)
             fusable = all(c.kind == "up" or (c.kind == "conv" and not c.learned) for c in cons[node.out])
             o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1)
                            and ho * wo <= self.fuse_maxpix and not split_out)
@@ -769,8 +778,13 @@ class Engine:
                         cs2 = (C.c_int32 * 2)(srcs[0].C, srcs[1].C)
                         L.call("mc_concat_cb8", ptrs, cs2, 2, N, srcs[0].H, srcs[0].W, self.mc_dtype, L.ptr(e["cat0"]), st)
                         x0 = e["cat0"]
-                    L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(x0), L.ptr(srcs[-1].lo), None,
-                           L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), None, L.ptr(e["part"]) if need_part else None, None, st)
+                    if e.get("x1b"):
+                        pro = L.ConvPrologue(None, None, 0, 0, L.ptr(srcs[1].lo), srcs[1].C)
+                        L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf), C.byref(pro),
+                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), None, L.ptr(e["part"]) if need_part else None, None, st)
+                    else:
+                        L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(x0), L.ptr(srcs[-1].lo), None,
+                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), None, L.ptr(e["part"]) if need_part else None, None, st)
                 else:
                     x0, x1, pro = self._sources(srcs)
                     L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(yout), None,
@@ -784,6 +798,8 @@ class Engine:
                 L.call("mc_gn_act_split_fwd", L.ptr(e["Yf"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
                        L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(e["Y"]), L.ptr(o.buf), L.ptr(e["lo"]), st)
                 if node.pool > 1:
+                    # (AvgPool2d inside the split pass -- one thread per 2 x 2 block -- measured 0.17 ms SLOWER than this
+                    # separate pass: the block-wise access pattern halves the coalescing of the 1.3 GB the split pass moves)
                     L.call("mc_avgpool_fwd", L.ptr(o.buf), N, node.c_out, o.H, o.W, node.pool, self.mc_dtype,
                            L.ptr(T[node.pooled].buf), st)
             elif o.fused:
@@ -1013,11 +1029,13 @@ class Engine:
             w = self._param(params, e["node"].name + "weight")
             if "fdesc" in e:
                 fd = e["fdesc"]
-                ci, cs = w.shape[1], fd.c_in1            # the last cs input channels are the split source
+                ci = w.shape[1]
+                tot = fd.c_in0 + fd.c_in1                # channels the launch sees: [sources ..., lo of the last source]
+                cs = fd.c_in1 // 2 if e.get("x1b") else fd.c_in1      # the last cs input channels are the split source
                 if e["w2"] is None:
-                    e["w2"] = torch.zeros((w.shape[0], fd.c_in0 + cs, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
-                e["w2"][:, :ci].copy_(w)                 # (channels ci .. c_in0 stay zero: padding of a lone 10-channel input)
-                e["w2"][:, fd.c_in0:].copy_(w[:, ci - cs:])
+                    e["w2"] = torch.zeros((w.shape[0], tot, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
+                e["w2"][:, :ci].copy_(w)                 # (channels ci .. tot - cs stay zero: padding of a lone 10-channel input)
+                e["w2"][:, tot - cs:].copy_(w[:, ci - cs:])
                 jobs.append((fd, L.ptr(e["w2"]), 0, L.ptr(e["fbank"])))
             else:
                 jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))

@@ -270,3 +270,61 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
         ref = got
     err = float((_from_cb8(dy, c).double() - ref).abs().max())
     assert err <= (1e-2 if dt == "bf16" else 2e-5) * float(ref.abs().max()), err
+
+
+@pytest.mark.parametrize("hw", [(37, 70), (20, 140)])
+def test_source_one_in_two_tensors_matches_the_materialised_concat(hw):
+    """mc_conv_prologue.x1b (row-reuse kernel): [up ++ hi] ++ lo read from three tensors == the same conv on
+    concat(up, hi) and lo — what the split-precision ("mixed") decoder conv uses; also the split activation kernel."""
+    from pbml_mantle_convection_amd import _lib as L
+    lib = L.load()
+    N, (H, W), C0, CS, CO, K = 2, hw, 16, 16, 16, 5
+    g = torch.Generator().manual_seed(7)
+    up = _cb8(torch.randn((N, C0, H, W), generator=g), torch.bfloat16)
+    a = torch.randn((N, CS, H, W), generator=g)
+    hi_f = a.to(torch.bfloat16).float()
+    hi, lo = _cb8(hi_f, torch.bfloat16), _cb8(a - hi_f, torch.bfloat16)
+    w = (torch.randn((CO, C0 + CS, K, K), generator=g) * 0.05).to(DEV)
+    w2 = torch.cat([w, w[:, C0:]], 1).contiguous()
+    bias = torch.randn(CO, generator=g).to(DEV)
+    st = L.stream()
+
+    def run(desc, x0, x1, pro):
+        assert L.call("mc_conv_tiles", C.byref(desc)) > 0
+        bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(desc), 0), dtype=torch.uint8, device=DEV)
+        L.call("mc_pack_weights", C.byref(desc), L.ptr(w2), 0, L.ptr(bank), st)
+        y = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.float32, device=DEV)
+        L.call("mc_conv2d_fused", C.byref(desc), L.ptr(x0), L.ptr(x1), pro, L.ptr(bank), L.ptr(bias), L.ptr(y), None, None, None, st)
+        torch.cuda.synchronize()
+        return y
+
+    d3 = L.ConvDesc(N, H, W, C0, 2 * CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
+    assert lib.mc_conv_kernel_name(C.byref(d3)).decode().startswith("k_conv_rr")
+    pro = L.ConvPrologue(None, None, 0, 0, L.ptr(lo), CS)
+    y3 = run(d3, up, hi, C.byref(pro))
+    cat0 = torch.cat([up, hi], 1).contiguous()
+    d2 = L.ConvDesc(N, H, W, C0 + CS, CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
+    y2 = run(d2, cat0, lo, None)
+    assert torch.equal(y3, y2)
+    # and against fp64 on the same (hi + lo) operand: the pair carries a to ~2^-17
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(torch.cat([_from_cb8(up, C0), hi_f + _from_cb8(lo, CS)], 1).double(),
+                                                             (2, 2, 2, 2), mode="reflect"),
+                                     w.cpu().to(torch.bfloat16).double(), bias.cpu().double())
+    assert float((_from_cb8(y3, CO).double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    # a launch that cannot honour x1b must refuse it
+    dsmall = L.ConvDesc(N, 12, 20, C0, 2 * CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
+    if not lib.mc_conv_kernel_name(C.byref(dsmall)).decode().startswith("k_conv_rr"):
+        bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(dsmall), 0), dtype=torch.uint8, device=DEV)
+        rc = lib.mc_conv2d_fused(C.byref(dsmall), L.ptr(up), L.ptr(hi), C.byref(pro), L.ptr(bank), L.ptr(bias), L.ptr(y3), None, None,
+                                 None, st)
+        assert rc == -2, rc
+
+    # the split activation: hi + lo carries act(y) to ~2^-17, y_bf16 is the rounded raw output
+    yf = torch.randn((N, CS // 8, H, W, 8), generator=g).to(DEV)
+    yb, h_, l_ = (torch.zeros((N, CS // 8, H, W, 8), dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    L.call("mc_gn_act_split_fwd", L.ptr(yf), N, CS, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(yb), L.ptr(h_),
+           L.ptr(l_), st)
+    torch.cuda.synchronize()
+    act = torch.nn.functional.gelu(_from_cb8(yf, CS).double())
+    assert float((_from_cb8(h_, CS).double() + _from_cb8(l_, CS).double() - act).abs().max()) <= 3e-4
+    assert torch.equal(yb, yf.to(torch.bfloat16))
