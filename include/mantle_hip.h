@@ -346,6 +346,14 @@ int mc_assemble_adtime_batch(const float* T, const float* uv, const float* t, co
                              const float* xc, const float* yc, const int32_t* pairs, int32_t b, int32_t m, int32_t cy,
                              int32_t h, int32_t w, float* x, float* y, float* scaler, float* paras_out, void* stream);
 
+/* The FluidNet family's dataset (NewADDataset.__getitem__, datasetio.py:595-654), same residency: T [m][h][w], uvp
+ * [m][cy][h][w] (cy = 2 or 3: u, v[, p]), t [m] (the item's time weight).  For every item idx[b] writes
+ *   x [b][7][h][w] = (xc/4, yc/4, log10(clip(eta,1e-8,1))/8, paras_nd x3, T),  y [b][cy][h][w] = (u/s, v/s[, p]),
+ *   t_weight [b] = t[idx], scaler [b] = s.  (The reference's optional 1e-5 input noise is host-side and not reproduced.) */
+int mc_assemble_newad_batch(const float* T, const float* uvp, const float* t, const float* paras, const float* paras_nd,
+                            const float* xc, const float* yc, const int32_t* idx, int32_t b, int32_t m, int32_t cy,
+                            int32_t h, int32_t w, float* x, float* y, float* t_weight, float* scaler, void* stream);
+
 /* ---- inference rollout (TS.forward / ADNet.forward, pytorch_networks_convae.py:266-568) ----------
  * Input builder of the 'newfluidnet' branch (:372-395): out [n][7][h][w] = (xc/4, yc/4, log10(clip(eta,1e-8,1))/8, nd0, nd1,
  * nd2, T) with eta = exp(-ln(FKT) T + ln(FKP) (1 - ycc)); T [n][h][w], xc/yc/ycc [h][w], paras [n][3] = (RaQ, FKT, FKP),

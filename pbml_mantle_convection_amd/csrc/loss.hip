@@ -393,6 +393,39 @@ __global__ void k_assemble_adtime(const float* __restrict__ T, const float* __re
   }
 }
 
+// on-device batch assembly for the FluidNet family (NewADDataset.__getitem__, datasetio.py:595-654)
+__global__ void k_assemble_newad(const float* __restrict__ T, const float* __restrict__ uvp, const float* __restrict__ t,
+                                 const float* __restrict__ paras, const float* __restrict__ paras_nd,
+                                 const float* __restrict__ xc, const float* __restrict__ yc, const int* __restrict__ idx,
+                                 int cy, int HW, float* __restrict__ x, float* __restrict__ y, float* __restrict__ tw,
+                                 float* __restrict__ scaler) {
+  const int b = blockIdx.y, i0 = idx[b];
+  const float raq = paras[i0 * 3], fkt = paras[i0 * 3 + 1], fkp = paras[i0 * 3 + 2];
+  const float lnfkt = logf(fkt), lnfkp = logf(fkp);
+  const float s = 5.0f * expf(raq * 0.1f * 1.80167667f + lnfkt * 0.4330392f + lnfkp * -0.46052953f);
+  const float inv_s = 1.0f / s;
+  const float n0 = paras_nd[i0 * 3], n1 = paras_nd[i0 * 3 + 1], n2 = paras_nd[i0 * 3 + 2];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scaler[b] = s; tw[b] = t[i0]; }
+  const float* T0 = T + (size_t)i0 * HW;
+  const float* yi = uvp + (size_t)i0 * cy * HW;
+  float* xb = x + (size_t)b * 7 * HW;
+  float* yb = y + (size_t)b * cy * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const float Tp = T0[i], ycv = yc[i];
+    const float eta = expf(-lnfkt * Tp + lnfkp * (1.0f - ycv));
+    xb[i] = xc[i] * 0.25f;
+    xb[HW + i] = ycv * 0.25f;
+    xb[2 * (size_t)HW + i] = log10f(fminf(fmaxf(eta, 1e-8f), 1.0f)) * 0.125f;
+    xb[3 * (size_t)HW + i] = n0;
+    xb[4 * (size_t)HW + i] = n1;
+    xb[5 * (size_t)HW + i] = n2;
+    xb[6 * (size_t)HW + i] = Tp;
+    yb[i] = yi[i] * inv_s;
+    yb[HW + i] = yi[HW + i] * inv_s;
+    if (cy > 2) yb[2 * (size_t)HW + i] = yi[2 * (size_t)HW + i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // inference rollout: TS input builder and the ADNet step (pytorch_networks_convae.py:372-395, 522-568)
 // ------------------------------------------------------------------------------------------------
@@ -591,6 +624,18 @@ int mc_assemble_adtime_batch(const float* T, const float* uv, const float* t, co
   dim3 grid(max(1, min(cdiv(h * w, 256 * 4), 256)), b);
   hipLaunchKernelGGL(k_assemble_adtime, grid, dim3(256), 0, (hipStream_t)stream, T, uv, t, paras, paras_nd, xc, yc, pairs, cy,
                      h * w, x, y, scaler, paras_out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_assemble_newad_batch(const float* T, const float* uvp, const float* t, const float* paras, const float* paras_nd,
+                            const float* xc, const float* yc, const int32_t* idx, int32_t b, int32_t m, int32_t cy, int32_t h,
+                            int32_t w, float* x, float* y, float* t_weight, float* scaler, void* stream) {
+  if (!T || !uvp || !t || !paras || !paras_nd || !xc || !yc || !idx || !x || !y || !t_weight || !scaler) return MC_EINVAL;
+  if (b <= 0 || m <= 0 || cy < 2 || cy > 3 || h <= 0 || w <= 0) return MC_EINVAL;
+  dim3 grid(max(1, min(cdiv(h * w, 256 * 4), 256)), b);
+  hipLaunchKernelGGL(k_assemble_newad, grid, dim3(256), 0, (hipStream_t)stream, T, uvp, t, paras, paras_nd, xc, yc, idx, cy, h * w,
+                     x, y, t_weight, scaler);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -170,13 +170,28 @@ class ADTimeDataset(Dataset, _GridMixin):
 
 
 class NewADDataset(Dataset, _GridMixin):
-    """Sub-sampled snapshots T -> (u, v[, p]) for the FluidNet family (reference :320-654)."""
+    """Sub-sampled snapshots T -> (u, v[, p]) for the FluidNet family (reference :320-654).  Shard files per simulation
+    directory `<data_dir>/<an>/sim_<n>/`: `times.pt`, `xc.pt`, `yc.pt`, and either the pre-selected snapshots
+    `e1_{u,v,p,T}prev_data_select[_init|_snaps].pt` with their original step indices `e1_i_vec_select[_init].pt`
+    (load=False, :475-583) or the full series `e1_{u,v,p,T}prev_data.pt` (load=True, :421-473).  Every item carries the
+    time weight 6 / (step + 1)^(1/4).  Pinned against the reference's own class on files in this layout by
+    tests/golden/g18_newad_dataset.npz."""
 
     def __init__(self, data_dir, an, scale=True, load=False, is_init=False, p_pred=True, noise=0.0, debug=True,
                  sims_vec=[], times_vec=[], max_examples_percent_per_epoch=100):
         self.y_data, self.x_data, self.t_data, self.paras, self.paras_nd = [], [], [], [], []
         self.scale, self.p_pred, self.noise = scale, p_pred, noise
-        suffix = "_select_init" if is_init else ("_select_snaps" if debug else "_select")
+        tv, sv = np.asarray(times_vec), np.asarray(sims_vec)
+
+        def add(i, step, u, v, p, Tp, paras, paras_nd):
+            self.paras.append(paras)
+            self.paras_nd.append(paras_nd)
+            self.x_data.append(Tp[i])
+            self.y_data.append(torch.cat((u[i], v[i], p[i]) if p_pred else (u[i], v[i]), axis=0))
+            # (`step` is an element of the loaded index tensor: integer-tensor ** 0.25 is evaluated in float32 by torch, and
+            # that float32 value is what the reference stores -- the same expression on the same type reproduces it)
+            self.t_data.append(torch.as_tensor(6 / (step + 1) ** 0.25).to(torch.float64).reshape(()))
+
         for si, sim in enumerate(_load(data_dir + "/sims.pt")):
             _, _, raq, fkt, fkp, _, _, _ = sim
             d = data_dir + "/" + sim[1] + "/sim_" + str(sim[0])
@@ -187,15 +202,42 @@ class NewADDataset(Dataset, _GridMixin):
             self._load_grid(d)
             paras = torch.tensor([raq, fkt, fkp], dtype=torch.float64).view(3, 1, 1)
             paras_nd = torch.tensor(normalise_parameters(raq, fkt, fkp), dtype=torch.float64).view(3, 1, 1)
+            if load:
+                # full series, sub-sampled here: the first 200 steps and up to 500 random later ones (:421-473)
+                from .scaler import scale_var
+                u, v = _load(d + "/e1_uprev_data.pt"), _load(d + "/e1_vprev_data.pt")
+                if scale:
+                    u, v = scale_var(u, raq, fkt, fkp, "uprev"), scale_var(v, raq, fkt, fkp, "vprev")
+                p = _load(d + "/e1_pprev_data.pt") if p_pred else None
+                Tp = _load(d + "/e1_Tprev_data.pt")
+                nt = len(times) - 2
+                if nt > 700:
+                    rest = list(range(200, nt))
+                    steps = list(range(1, 200)) + random.choices(rest, k=min(500, rest[-1] - 200))
+                else:
+                    steps = list(range(1, nt))
+                steps = steps[:5] if is_init else steps[5:]
+                if debug:
+                    steps = steps[-8:]
+                for i in steps:
+                    add(i, i, u, v, p, Tp, paras, paras_nd)
+                continue
+            if is_init:
+                suffix = "_select_init"
+            elif debug:
+                if p_pred:
+                    raise ValueError("p_pred is not implemented in debug mode")
+                suffix = "_select_snaps"
+            else:
+                suffix = "_select"
             u, v, Tp = (_load(d + f"/e1_{k}prev_data{suffix}.pt") for k in "uvT")
             p = _load(d + f"/e1_pprev_data{suffix}.pt") if p_pred else None
-            for i in range(u.shape[0]):
-                self.paras.append(paras)
-                self.paras_nd.append(paras_nd)
-                self.x_data.append(Tp[i])
-                self.y_data.append(torch.cat((u[i], v[i], p[i]) if p_pred else (u[i], v[i]), axis=0))
-                self.t_data.append(torch.tensor(float(times[min(i, len(times) - 1)]), dtype=torch.float64))
-        self.num_examples = int(len(self.y_data) * max_examples_percent_per_epoch / 100)
+            i_vec = np.arange(u.shape[0]) if suffix == "_select_snaps" else _load(d + f"/e1_i_vec{suffix}.pt")
+            mine = tv[sv == sim[0]] if len(sims_vec) > 0 else None
+            for i, step in enumerate(i_vec):
+                if mine is None or step in mine:
+                    add(i, step, u, v, p, Tp, paras, paras_nd)
+        self.num_examples = min(int(len(self.y_data) * max_examples_percent_per_epoch / 100), len(self.y_data))
         print("using ", self.num_examples, " out of ", len(self.y_data), " per epoch")
 
     def __len__(self):
@@ -283,6 +325,62 @@ class ResidentADTimeDataset:
                L.ptr(self.paras_nd), L.ptr(self.xc), L.ptr(self.yc), L.ptr(ptab), B, self.M, self.cy, self.H, self.W,
                L.ptr(x), L.ptr(y), L.ptr(sc), L.ptr(pa), L.stream())
         return x, y, sc, pa.view(B, 3, 1, 1) if pa.dim() == 2 else pa, self.yc.view(1, self.H, self.W)
+
+
+class ResidentNewADDataset:
+    """SURVEY 8(f) N2 for the FluidNet family: a `NewADDataset` kept resident in HBM, batches assembled ON the device by
+    `mc_assemble_newad_batch` (the reference builds every item on the host in fp64: datasetio.py:595-654).  Stored once as
+    f32: T [M,H,W], targets [M,cy,H,W] (u, v[, p]), time weights [M], parameters [M,3] (+ normalised), xc / yc [H,W].
+    `assemble(idx)` returns device tensors (x [B,7,H,W], y [B,cy,H,W], t_weight [B], scaler [B]) — the 4-tuple of
+    `NewADDataset.__getitem__`, batched — and can write x, y straight into `Trainer.input_buffers()`.  The reference's
+    optional `noise` (a 1e-5 uniform perturbation of T drawn with numpy on the host) is not reproduced: the constructor
+    refuses a dataset built with noise > 0."""
+
+    def __init__(self, ds: "NewADDataset", device):
+        from . import _lib as L
+        self._L = L
+        L.load()
+        if getattr(ds, "noise", 0.0) > 0:
+            raise NotImplementedError("NewADDataset(noise > 0) draws host-side numpy noise per item; keep noise = 0 for the "
+                                      "resident form")
+        if not ds.scale:
+            raise NotImplementedError("scale=False returns nothing in the reference either")
+        dev = torch.device(device)
+        f = dict(dtype=torch.float32, device=dev)
+        n = ds.num_examples
+        self.T = torch.stack([t.reshape(t.shape[-2], t.shape[-1]) for t in ds.x_data[:n]]).to(**f).contiguous()
+        self.uvp = torch.stack(list(ds.y_data[:n])).to(**f).contiguous()
+        self.t = torch.tensor([float(v) for v in ds.t_data[:n]], **f)
+        self.paras = torch.stack([p.reshape(3) for p in ds.paras[:n]]).to(**f).contiguous()
+        self.paras_nd = torch.stack([p.reshape(3) for p in ds.paras_nd[:n]]).to(**f).contiguous()
+        self.xc = ds.xc.reshape(ds.xc.shape[-2], ds.xc.shape[-1]).to(**f).contiguous()
+        self.yc = ds.yc.reshape(ds.yc.shape[-2], ds.yc.shape[-1]).to(**f).contiguous()
+        self.M, self.cy, self.H, self.W = self.T.shape[0], self.uvp.shape[1], self.T.shape[1], self.T.shape[2]
+        self.p_pred, self.device = ds.p_pred, dev
+
+    def __len__(self):
+        return self.M
+
+    def assemble(self, idx, out=None):
+        """idx: iterable of item indices.  out: optional dict with preallocated 'gVTp' [B,7,H,W] and 'uvp' [B,cy,H,W] f32
+        device tensors (e.g. Trainer.input_buffers())."""
+        L = self._L
+        idx = [int(i) for i in idx]
+        if not idx or min(idx) < 0 or max(idx) >= self.M:
+            raise IndexError("item index out of range")
+        B = len(idx)
+        itab = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
+        f = dict(dtype=torch.float32, device=self.device)
+        o = out or {}
+        x = o.get("gVTp") if o.get("gVTp") is not None else torch.empty((B, 7, self.H, self.W), **f)
+        y = o.get("uvp") if o.get("uvp") is not None else torch.empty((B, self.cy, self.H, self.W), **f)
+        if tuple(x.shape) != (B, 7, self.H, self.W) or tuple(y.shape) != (B, self.cy, self.H, self.W):
+            raise ValueError("output buffers do not match the batch shape")
+        tw, sc = torch.empty((B,), **f), torch.empty((B,), **f)
+        L.call("mc_assemble_newad_batch", L.ptr(self.T), L.ptr(self.uvp), L.ptr(self.t), L.ptr(self.paras), L.ptr(self.paras_nd),
+               L.ptr(self.xc), L.ptr(self.yc), L.ptr(itab), B, self.M, self.cy, self.H, self.W, L.ptr(x), L.ptr(y), L.ptr(tw),
+               L.ptr(sc), L.stream())
+        return x, y, tw, sc
 
 
 def synthetic_batch(B, H, W, seed, *, p_pred=True, device="cpu", dtype=torch.float32, channels=None):

@@ -455,7 +455,16 @@ def load_train_objs(rank, world_size, nn_dir, data_dir, levels, c_i, c_h, c_o, a
                                         roll_forward=roll_forward)
             dataset_init[an] = None
         else:
-            raise NotImplementedError("real-data loading is implemented for network='unet' (ADTimeDataset)")
+            # the FluidNet family trains on NewADDataset items (reference :684, 726-760)
+            kw = dict(scale=scale, p_pred=p_pred, noise=noise, debug=debug)
+            dataset[an] = NewADDataset(data_dir, an, is_init=False, sims_vec=sims_vec[an][lo:hi],  # noqa: F405
+                                       times_vec=times_vec[an][lo:hi], **kw)
+            if debug:
+                dataset_init[an] = None
+            else:
+                lo_i, hi_i = shard_range(len(sims_vec_init[an]), world_size, rank)
+                dataset_init[an] = NewADDataset(data_dir, an, is_init=True, sims_vec=sims_vec_init[an][lo_i:hi_i],  # noqa: F405
+                                                times_vec=times_vec_init[an][lo_i:hi_i], **kw)
     optimizer = torch.optim.Adam([{"params": model_uvp.parameters(), "lr": start_lr, "weight_decay": l2_reg}])
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=milestones, gamma=0.5)
     return dataset, dataset_init, model_uvp, None, optimizer, scheduler, epoch

@@ -555,10 +555,64 @@ def g17():
         **{k_: v.float() for k_, v in grads_np(m).items()})
 
 
+# ------------------------------------------------------------------ G18 NewADDataset on shard files in the reference's layout
+def g18():
+    """The reference's own `datasetio.NewADDataset` (datasetio.py:320-654) run on a tiny data directory written in ITS file
+    layout (sims.pt, <an>/sim_<n>/{times,xc,yc}.pt, e1_{u,v,p,T}prev_data_select[_init|_snaps].pt, e1_i_vec_select[_init].pt).
+    The fixture holds the file contents (so the test re-creates the directory) and every item the reference returns."""
+    import tempfile
+    import datasetio as D
+    H, W = 10, 14
+    g = torch.Generator().manual_seed(180)
+    sims = [(3, "train", 2.5, 1e7, 12.0, 0.0, 4.0, 0), (5, "cv", 6.0, 3e8, 40.0, 0.0, 4.0, 0), (7, "train", 8.5, 5e6, 3.0, 0.0, 4.0, 0)]
+    files = {}
+    root = tempfile.mkdtemp()
+    torch.save(sims, root + "/sims.pt")
+    yy, xx = torch.meshgrid(torch.linspace(0.02, 0.97, H, dtype=f64), torch.linspace(0.05, 3.9, W, dtype=f64), indexing="ij")
+    for num, an, *_ in sims:
+        d = f"{root}/{an}/sim_{num}"
+        os.makedirs(d)
+        content = {"times": torch.cumsum(torch.rand(9, generator=g, dtype=f64) * 1e-4, 0), "xc": xx.clone(), "yc": yy.clone()}
+        for suf, m in (("_select", 5), ("_select_init", 3), ("_select_snaps", 4)):
+            for k in "uvpT":
+                amp = {"u": 300.0, "v": 200.0, "p": 1.0, "T": 0.5}[k]
+                t = torch.rand((m, 1, H, W), generator=g, dtype=torch.float32).to(f64) * amp
+                content[f"e1_{k}prev_data{suf}"] = t
+            if suf != "_select_snaps":
+                content[f"e1_i_vec{suf}"] = torch.tensor(sorted(torch.randperm(40, generator=g)[:m].tolist()))
+        for k, v in content.items():
+            torch.save(v, f"{d}/{k}.pt")
+            files[f"file/{an}/sim_{num}/{k}"] = v
+    out = dict(files)
+    out["sims_num"] = np.array([s_[0] for s_ in sims]); out["sims_an"] = np.array([s_[1] for s_ in sims])
+    out["sims_par"] = np.array([[s_[2], s_[3], s_[4], s_[5], s_[6], s_[7]] for s_ in sims])
+    iv3 = files["file/train/sim_3/e1_i_vec_select"].tolist()
+    iv7 = files["file/train/sim_7/e1_i_vec_select"].tolist()
+    cases = {
+        "all": dict(an="train", is_init=False, p_pred=True, debug=False, sims_vec=[], times_vec=[]),
+        "init": dict(an="train", is_init=True, p_pred=True, debug=False, sims_vec=[], times_vec=[]),
+        "snaps": dict(an="train", is_init=False, p_pred=False, debug=True, sims_vec=[], times_vec=[]),
+        "cv": dict(an="cv", is_init=False, p_pred=False, debug=False, sims_vec=[], times_vec=[]),
+        "filtered": dict(an="train", is_init=False, p_pred=True, debug=False, sims_vec=[3, 3, 7], times_vec=[iv3[1], iv3[3], iv7[0]]),
+        "half": dict(an="train", is_init=False, p_pred=True, debug=False, sims_vec=[], times_vec=[], max_examples_percent_per_epoch=50),
+    }
+    for name, kw in cases.items():
+        ds = D.NewADDataset(root, scale=True, load=False, noise=0.0, **kw)
+        items = [ds[i] for i in range(len(ds))]
+        out[f"{name}/n"] = len(ds)
+        out[f"{name}/x"] = torch.stack([it[0] for it in items])
+        out[f"{name}/y"] = torch.stack([it[1] for it in items])
+        out[f"{name}/t"] = torch.stack([it[2].reshape(()) for it in items])
+        out[f"{name}/s"] = torch.stack([torch.as_tensor(it[3]).reshape(()) for it in items])
+        if name == "filtered":
+            out["filtered/sims_vec"] = np.array(kw["sims_vec"]); out["filtered/times_vec"] = np.array(kw["times_vec"])
+    npz("g18_newad_dataset", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18):
         if not only or fn.__name__ in only:
             fn()
