@@ -360,6 +360,14 @@ int mc_assemble_newad_batch(const float* T, const float* uvp, const float* t, co
  * paras_nd [n][3]. */
 int mc_ts_build_input(const float* T, const float* xc, const float* yc, const float* ycc, const float* paras,
                       const float* paras_nd, int32_t n, int32_t h, int32_t w, float* out, void* stream);
+/* Input builder of the 'unet' branch (:411-436): out [n][10][h][w] = (xc/4, yc/4, dt, nd0, nd1, nd2,
+ * log10(clip(eta,1e-8,1))/8, T, u_prev, v_prev); dt, u_prev, v_prev [n][h][w].  The network predicts the next T itself;
+ * mc_ts_wall_bc applies the wall rows (bottom 1, top 0) and copies the side columns from their inner neighbours
+ * (:441-444) out of place. */
+int mc_ts_build_input_unet(const float* T, const float* xc, const float* yc, const float* ycc, const float* paras,
+                           const float* paras_nd, const float* dt, const float* u_prev, const float* v_prev, int32_t n,
+                           int32_t h, int32_t w, float* out, void* stream);
+int mc_ts_wall_bc(const float* t_in, int32_t n, int32_t h, int32_t w, float* t_out, void* stream);
 /* One explicit upwind advection-diffusion step (ADNet.forward :522-568) on the non-uniform grid xc / yc [h][w] (wall
  * coordinates 0 / 4 and 0 / 1 are substituted on the fly, as the reference writes them into its inputs): u, v [n][h][w]
  * with batch stride uv_stride, multiplied by vel_scale[n] (NULL = 1: TS un-scales the network's velocities, :397-398);

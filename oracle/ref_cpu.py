@@ -753,6 +753,27 @@ def ts_rollout(stokes, T_prev, ycc, raq_nd, fkt_nd, fkp_nd, raq, fkt, fkp, xc, y
     return x, dts, u, v, p, V
 
 
+def ts_rollout_unet(stokes, T_prev, ycc, raq_nd, fkt_nd, fkp_nd, fkt, fkp, xc, yc, u_prev, v_prev, dt, ts: int):
+    """TS.forward, 'unet' branch (:411-446): the Stokes net predicts the next T itself; u_prev, v_prev and dt are the
+    caller's for every step, no advection net, p = None, V = the last input's viscosity channel log10(clip(eta))/8.
+    `stokes(inp)` returns (u, v, p, T)."""
+    B, _, H, W = T_prev.shape
+    x = {0: T_prev}
+    u = v = V = None
+    for i in range(1, ts + 1):
+        V = torch.log10(torch.clip(eta_torch(fkt, fkp, 1.0 - ycc, x[i - 1]), 1e-8, 1.0)) / 8.0
+        inp = torch.cat((xc / 4.0, yc / 4.0, dt, raq_nd.expand(1, 1, H, W), fkt_nd.expand(1, 1, H, W), fkp_nd.expand(1, 1, H, W),
+                         V, x[i - 1], u_prev, v_prev), dim=1)
+        u, v, _, T = stokes(inp)
+        Tn = T.reshape(B, 1, H, W).clone()
+        Tn[:, :, 0, :] = 1
+        Tn[:, :, -1, :] = 0
+        Tn[:, :, :, 0:1] = Tn[:, :, :, 1:2]
+        Tn[:, :, :, -1:] = Tn[:, :, :, -2:-1]
+        x[i] = Tn
+    return x, {}, u.reshape(B, 1, H, W), v.reshape(B, 1, H, W), None, V
+
+
 # --------------------------------------------------------------------------------------
 # Stokes momentum residual — BUILD-DEFINED (SURVEY.md row A12; no reference implementation)
 # --------------------------------------------------------------------------------------

@@ -393,6 +393,42 @@ __global__ void k_assemble_adtime(const float* __restrict__ T, const float* __re
   }
 }
 
+// TS 'unet' branch (pytorch_networks_convae.py:411-446): 10-channel input and the wall / side conditions of the predicted T
+__global__ void k_ts_build_input_unet(const float* __restrict__ T, const float* __restrict__ xc, const float* __restrict__ yc,
+                                      const float* __restrict__ ycc, const float* __restrict__ paras, const float* __restrict__ nd,
+                                      const float* __restrict__ dt, const float* __restrict__ up, const float* __restrict__ vp,
+                                      int HW, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float lnfkt = logf(paras[n * 3 + 1]), lnfkp = logf(paras[n * 3 + 2]);
+  const float n0 = nd[n * 3], n1 = nd[n * 3 + 1], n2 = nd[n * 3 + 2];
+  const float* Tn = T + (size_t)n * HW;
+  float* o = out + (size_t)n * 10 * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const float t = Tn[i];
+    const float eta = fminf(fmaxf(expf(-lnfkt * t + lnfkp * (1.0f - ycc[i])), 1e-8f), 1.0f);
+    o[i] = xc[i] * 0.25f;
+    o[HW + i] = yc[i] * 0.25f;
+    o[2 * (size_t)HW + i] = dt[(size_t)n * HW + i];
+    o[3 * (size_t)HW + i] = n0;
+    o[4 * (size_t)HW + i] = n1;
+    o[5 * (size_t)HW + i] = n2;
+    o[6 * (size_t)HW + i] = log10f(eta) * 0.125f;
+    o[7 * (size_t)HW + i] = t;
+    o[8 * (size_t)HW + i] = up[(size_t)n * HW + i];
+    o[9 * (size_t)HW + i] = vp[(size_t)n * HW + i];
+  }
+}
+// T[:, 0, :] = 1, T[:, -1, :] = 0, then the side columns copy their inner neighbours (:441-444); one block per sample
+__global__ void k_ts_wall_bc(const float* __restrict__ src, int H, int W, float* __restrict__ dst) {
+  const float* s = src + (size_t)blockIdx.x * H * W;
+  float* d = dst + (size_t)blockIdx.x * H * W;
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    const int xs = x == 0 ? 1 : (x == W - 1 ? W - 2 : x);
+    d[i] = y == 0 ? 1.f : (y == H - 1 ? 0.f : s[(size_t)y * W + xs]);
+  }
+}
+
 // on-device batch assembly for the FluidNet family (NewADDataset.__getitem__, datasetio.py:595-654)
 __global__ void k_assemble_newad(const float* __restrict__ T, const float* __restrict__ uvp, const float* __restrict__ t,
                                  const float* __restrict__ paras, const float* __restrict__ paras_nd,
@@ -645,6 +681,25 @@ int mc_ts_build_input(const float* T, const float* xc, const float* yc, const fl
   if (!T || !xc || !yc || !ycc || !paras || !paras_nd || !out || n <= 0 || h <= 0 || w <= 0) return MC_EINVAL;
   dim3 grid(max(1, min(cdiv(h * w, 256), 1024)), n);
   hipLaunchKernelGGL(k_ts_build_input, grid, dim3(256), 0, (hipStream_t)stream, T, xc, yc, ycc, paras, paras_nd, h * w, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_ts_build_input_unet(const float* T, const float* xc, const float* yc, const float* ycc, const float* paras,
+                           const float* paras_nd, const float* dt, const float* u_prev, const float* v_prev, int32_t n, int32_t h,
+                           int32_t w, float* out, void* stream) {
+  if (!T || !xc || !yc || !ycc || !paras || !paras_nd || !dt || !u_prev || !v_prev || !out || n <= 0 || h <= 0 || w <= 0)
+    return MC_EINVAL;
+  dim3 grid(max(1, min(cdiv(h * w, 256), 1024)), n);
+  hipLaunchKernelGGL(k_ts_build_input_unet, grid, dim3(256), 0, (hipStream_t)stream, T, xc, yc, ycc, paras, paras_nd, dt, u_prev,
+                     v_prev, h * w, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_ts_wall_bc(const float* t_in, int32_t n, int32_t h, int32_t w, float* t_out, void* stream) {
+  if (!t_in || !t_out || n <= 0 || h < 2 || w < 3 || t_in == t_out) return MC_EINVAL;
+  hipLaunchKernelGGL(k_ts_wall_bc, dim3(n), dim3(1024), 0, (hipStream_t)stream, t_in, h, w, t_out);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -426,9 +426,9 @@ class TS(nn.Module):
     def __init__(self, stokes, ad, device, ts=8, advection_scheme=2, scale=True, p_pred=True, net="fluidnet", use_graph=False):
         super().__init__()
         self.use_graph, self._g = bool(use_graph), None        # use_graph: one rollout step captured as a HIP graph and replayed
-        if net not in ("newfluidnet",):
-            raise NotImplementedError("TS on the HIP path covers net='newfluidnet' (the deployed configuration)")
-        if ad is None:
+        if net not in ("newfluidnet", "unet"):
+            raise NotImplementedError("TS on the HIP path covers net='newfluidnet' (the deployed configuration) and 'unet'")
+        if ad is None and net == "newfluidnet":
             raise NotImplementedError("TS needs the advection net (ADNet)")
         self.stokes, self.ad, self.ts, self.device = stokes, ad, ts, device
         self.advection_scheme, self.scale, self.p_pred, self.net = advection_scheme, scale, p_pred, net
@@ -436,6 +436,8 @@ class TS(nn.Module):
     @torch.no_grad()
     def forward(self, T_prev, sdf, sdf2, ycc, raq_nd, fkt_nd, fkp_nd, raq, fkt, fkp, xc, yc, u_prev=None, v_prev=None,
                 dt=None):
+        if self.net == "unet":
+            return self._forward_unet(T_prev, ycc, raq_nd, fkt_nd, fkp_nd, raq, fkt, fkp, xc, yc, u_prev, v_prev, dt)
         dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
         f = dict(dtype=torch.float32, device=dev)
         B, _, H, W = T_prev.shape
@@ -495,6 +497,38 @@ class TS(nn.Module):
         sv = scaler.view(B, 1, 1, 1)
         return (x, dts, u.view(B, 1, H, W) * sv, v.view(B, 1, H, W) * sv,
                 p.reshape(B, 1, H, W) if (p is not None and self.p_pred) else p, V)
+
+
+    def _forward_unet(self, T_prev, ycc, raq_nd, fkt_nd, fkp_nd, raq, fkt, fkp, xc, yc, u_prev, v_prev, dt):
+        """The 'unet' branch (reference :411-446): the Stokes net predicts the next temperature itself — ts times
+        { 10-channel input (xc/4, yc/4, dt, normalised parameters, log10(clip(eta))/8, T, u_prev, v_prev) -> Unet -> wall rows
+        and side columns of T }.  As in the reference, u_prev / v_prev / dt stay the caller's for every step, no advection net
+        runs, p is None and the returned V is the LAST input's viscosity channel (already log-scaled).  The reference
+        hard-codes a 1 x 1 x 128 x 506 view; any [B, 1, H, W] works here."""
+        if u_prev is None or v_prev is None or dt is None:
+            raise ValueError("TS(net='unet') needs u_prev, v_prev and dt")
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        f = dict(dtype=torch.float32, device=dev)
+        B, _, H, W = T_prev.shape
+        plane = lambda t: torch.as_tensor(t).to(**f).reshape(-1, H, W)[0].contiguous()  # noqa: E731
+        full = lambda t: torch.as_tensor(t).to(**f).expand(B, 1, H, W).reshape(B, H, W).contiguous()  # noqa: E731
+        xcp, ycp, yccp = plane(xc), plane(yc), plane(ycc)
+        sc3 = lambda a, b, c: torch.stack([torch.as_tensor(t, dtype=torch.float32).reshape(-1)[:1].expand(B) for t in (a, b, c)],  # noqa: E731
+                                          1).to(**f).contiguous()
+        paras, nd = sc3(raq, fkt, fkp), sc3(raq_nd, fkt_nd, fkp_nd)
+        dtp, up, vp = full(dt), full(u_prev), full(v_prev)
+        inp = torch.empty((B, 10, H, W), **f)
+        x = {0: T_prev.to(**f).reshape(B, 1, H, W).contiguous()}
+        u = v = None
+        for i in range(1, self.ts + 1):
+            L.call("mc_ts_build_input_unet", L.ptr(x[i - 1]), L.ptr(xcp), L.ptr(ycp), L.ptr(yccp), L.ptr(paras), L.ptr(nd), L.ptr(dtp),
+                   L.ptr(up), L.ptr(vp), B, H, W, L.ptr(inp), L.stream())
+            u, v, _, Tn = self.stokes(inp)
+            Tn = Tn.reshape(B, H, W).to(**f).contiguous()
+            x[i] = torch.empty((B, 1, H, W), **f)
+            L.call("mc_ts_wall_bc", L.ptr(Tn), B, H, W, L.ptr(x[i]), L.stream())
+        V = inp[:, 6:7].clone() if self.ts >= 1 else None
+        return x, {}, u.reshape(B, 1, H, W), v.reshape(B, 1, H, W), None, V
 
 
 # --------------------------------------------------------------------------------------------------

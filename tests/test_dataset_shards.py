@@ -107,3 +107,61 @@ def test_resident_newad_dataset_assembles_batches_on_device(golden, tmp_path, na
     assert x2.data_ptr() == out["gVTp"].data_ptr() and torch.equal(x2, x) and torch.equal(y2, y)
     with pytest.raises(IndexError):
         res.assemble([len(ds)])
+
+
+AD_CASES = {
+    "all": dict(an="train", p_pred=True, debug=False, roll_forward=1),
+    "roll2": dict(an="train", p_pred=False, debug=False, roll_forward=2),
+    "debug": dict(an="cv", p_pred=False, debug=True, roll_forward=1),
+    "filtered": dict(an="train", p_pred=True, debug=False, roll_forward=1),
+}
+
+
+def _adtime(golden, tmp_path, name):
+    from pbml_mantle_convection_amd.datasetio import ADTimeDataset
+    g = golden("g19_adtime_dataset")
+    _write_tree(g, str(tmp_path))
+    kw = dict(AD_CASES[name])
+    if name == "filtered":
+        kw.update(sims_vec=g["filtered/sims_vec"].tolist(), times_vec=g["filtered/times_vec"].tolist())
+    return g, ADTimeDataset(str(tmp_path), scale=True, load=False, noise=0.0, **kw)
+
+
+@pytest.mark.parametrize("name", list(AD_CASES))
+def test_adtime_dataset_matches_reference_items(golden, tmp_path, name):
+    """ADTimeDataset (the U-Net's dataset, reference datasetio.py:63-280) read from files in the reference's layout: index
+    pairs, initial-condition pairs and every item equal to what the reference's class returned (g19)."""
+    import random
+    g, ds = _adtime(golden, tmp_path, name)
+    assert len(ds) == int(g[f"{name}/n"])
+    assert np.array_equal(np.array(ds.indices).reshape(-1, 2), g[f"{name}/indices"])
+    assert np.array_equal(np.array(ds.indices_init).reshape(-1, 2), g[f"{name}/indices_init"])
+    for i in range(len(ds)):
+        random.seed(1000 + i)
+        x, y, s, paras, yc = ds[i]
+        np.testing.assert_allclose(x.numpy(), g[f"{name}/x"][i], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(y.numpy(), g[f"{name}/y"][i], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(float(torch.as_tensor(s).reshape(())), g[f"{name}/s"][i], rtol=1e-12)
+        np.testing.assert_allclose(paras.reshape(3).numpy(), g[f"{name}/paras"][i], rtol=1e-14)
+        np.testing.assert_allclose(yc.numpy(), g[f"{name}/yc"], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_resident_adtime_dataset_on_reference_layout_files(golden, tmp_path):
+    """The HBM-resident form fed from shard files (not synthetic members): device batches == stacked host items."""
+    import random
+    from pbml_mantle_convection_amd.datasetio import ResidentADTimeDataset
+    g, ds = _adtime(golden, tmp_path, "all")
+    res = ResidentADTimeDataset(ds, "cuda:0")
+    idx = [1, 2, 3, 5]                                   # (items whose first index is a multiple of 8 draw a random pair)
+    pairs = [tuple(ds.indices[i]) for i in idx]
+    x, y, sc, pa, yc = res.assemble(idx, pairs=pairs)
+    torch.cuda.synchronize()
+    for b, i in enumerate(idx):
+        if ds.indices[i][0] % 8 == 0:
+            continue
+        random.seed(0)
+        xr, yr, sr, pr, ycr = ds[i]
+        np.testing.assert_allclose(x[b].cpu().numpy(), xr.numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(y[b].cpu().numpy(), yr.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(float(sc[b]), float(torch.as_tensor(sr).reshape(())), rtol=2e-5)

@@ -273,6 +273,38 @@ def test_ts_rollout_newfluidnet_vs_oracle(golden):
     assert_close(V, Vr.numpy(), atol=1e-6, rtol=1e-4, what="V")
 
 
+def test_ts_rollout_unet_branch_vs_oracle():
+    """TS(net='unet') (reference :411-446): input builder -> Unet on the HIP path -> wall conditions, three steps, against the
+    oracle's restatement of that branch (pinned by g20) driving the oracle's Unet with the same weights."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import TS, Unet
+    torch.manual_seed(5)
+    H, W = 128, 506
+    m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", "mae", use_symm=True, repeats=2, f=5, p_pred=True).to(DEV)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    xc, yc = (torch.from_numpy(a) for a in _n3_grid(H, W))
+    T0 = torch.from_numpy(fields.temperature_field(1, H, W, 2100)).view(1, 1, H, W)
+    up = torch.from_numpy(fields.smooth_field(1, H, W, 2101)).view(1, 1, H, W)
+    vp = torch.from_numpy(fields.smooth_field(1, H, W, 2102)).view(1, 1, H, W)
+    dt = torch.full((1, 1, H, W), 3e-5, dtype=torch.float64)
+    raq, fkt, fkp = (torch.tensor(v, dtype=torch.float64) for v in (2.5, 1e7, 30.0))
+    nd = [torch.tensor(v, dtype=torch.float64).view(1, 1, 1, 1) for v in (0.25, 0.26, 0.74)]
+
+    def stokes_ref(inp):
+        return O.unet_forward(sd, inp, levels=3, repeats=2, act="gelu", r_p="reflect", loss_type="mae", use_symm=True, p_pred=True)
+
+    xr, _, ur, vr, _, Vr = O.ts_rollout_unet(stokes_ref, T0, yc, nd[0], nd[1], nd[2], fkt, fkp, xc, yc, up, vp, dt, ts=3)
+    ts = TS(m, None, DEV, ts=3, net="unet")
+    x, dts, u, v, p, V = ts(T0, None, None, yc, nd[0], nd[1], nd[2], raq, fkt, fkp, xc, yc, u_prev=up, v_prev=vp, dt=dt)
+    assert p is None and dts == {}
+    for i in (1, 2, 3):
+        assert_close(x[i], xr[i].numpy(), atol=3e-5, rtol=0, what=f"T step {i}")
+    assert_close(u, ur.numpy(), atol=3e-5, rtol=1e-4, what="u")
+    assert_close(v, vr.numpy(), atol=3e-5, rtol=1e-4, what="v")
+    assert_close(V, Vr.numpy(), atol=1e-6, rtol=1e-4, what="V")
+    with pytest.raises(ValueError):
+        ts(T0, None, None, yc, nd[0], nd[1], nd[2], raq, fkt, fkp, xc, yc)
+
+
 def test_ts_rollout_graph_replay_equals_eager():
     """One rollout step captured as a HIP graph and replayed gives bit-identical fields to eager launches, also on a second
     call with fresh argument tensors (the captured step must read persistent buffers, not the caller's temporaries)."""

@@ -413,6 +413,33 @@ def test_ts_rollout(golden):
     close(smp(V), g["V"], atol=1e-12)
 
 
+def test_ts_rollout_unet_branch(golden):
+    """TS.forward 'unet' branch (:411-446): the net predicts T itself; pinned with a stub network run through the reference."""
+    g = golden("g20_ts_rollout_unet")
+    H, W = 128, 506
+    xc, yc = _n3_grid(H, W)
+    T0 = T(fields.temperature_field(1, H, W, 2000)).view(1, 1, H, W)
+    up = T(fields.smooth_field(1, H, W, 2001)).view(1, 1, H, W)
+    vp = T(fields.smooth_field(1, H, W, 2002)).view(1, 1, H, W)
+    dt = torch.full((1, 1, H, W), float(g["dt"]), dtype=torch.float64)
+    _, fkt, fkp = (torch.tensor(float(v), dtype=torch.float64) for v in g["paras"])
+    nd = [torch.tensor(float(v), dtype=torch.float64).view(1, 1, 1, 1) for v in g["nd"]]
+
+    def stub(inp):
+        Tc, u0, v0, d, V = inp[:, 7], inp[:, 8], inp[:, 9], inp[:, 2], inp[:, 6]
+        return u0 * 0.9 + 0.1 * Tc, v0 * 0.8 - 0.05 * Tc, None, Tc + d * (torch.roll(Tc, 1, dims=2) - Tc) * 50.0 + 0.01 * V
+
+    x, dts, u, v, p, V = O.ts_rollout_unet(stub, T0, yc, nd[0], nd[1], nd[2], fkt, fkp, xc, yc, up, vp, dt, ts=3)
+    assert p is None and dts == {}
+    smp = lambda t: fields.strided_sample(t.numpy(), 4001)  # noqa: E731
+    close(smp(x[1]), g["T1"], atol=1e-12)
+    close(smp(x[2]), g["T2"], atol=1e-12)
+    close(x[3], g["T3"], atol=1e-12)
+    close(smp(u), g["u"], atol=1e-12)
+    close(smp(v), g["v"], atol=1e-12)
+    close(smp(V), g["V"], atol=1e-12)
+
+
 @pytest.mark.parametrize("tag", ["k5_symm", "k3_plain"])
 def test_boundary_learned_conv(golden, tag):
     """the "learned padding" layer (nine valid convolutions framed together) vs the imported reference."""

@@ -494,6 +494,34 @@ def g15():
         nd=np.array([0.25, 0.26, 0.74]), paras=np.array([2.5, 1e7, 30.0]))
 
 
+class _UnetStub(torch.nn.Module):
+    """Stand-in for the U-Net of the TS 'unet' branch: (u, v, p, T_next) as smooth functions of the 10-channel input."""
+
+    def forward(self, inp):
+        T, up, vp, dt, V = inp[:, 7], inp[:, 8], inp[:, 9], inp[:, 2], inp[:, 6]
+        Tn = T + dt * (torch.roll(T, 1, dims=2) - T) * 50.0 + 0.01 * V
+        return up * 0.9 + 0.1 * T, vp * 0.8 - 0.05 * T, None, Tn
+
+
+def g20():
+    """TS(net='unet') of the reference (:411-446) with a stub network: pins the oracle's restatement of that branch."""
+    H, W = 128, 506
+    xc, yc = _grid(H, W)
+    T0 = torch.from_numpy(fields.temperature_field(1, H, W, 2000)).view(1, 1, H, W)
+    up = torch.from_numpy(fields.smooth_field(1, H, W, 2001)).view(1, 1, H, W)
+    vp = torch.from_numpy(fields.smooth_field(1, H, W, 2002)).view(1, 1, H, W)
+    dt = torch.full((1, 1, H, W), 3e-5, dtype=f64)
+    raq, fkt, fkp = (torch.tensor(v, dtype=f64) for v in (2.5, 1e7, 30.0))
+    nd = [torch.tensor(v, dtype=f64).view(1, 1, 1, 1) for v in (0.25, 0.26, 0.74)]
+    ts = P.TS(_UnetStub(), None, CPU, ts=3, net="unet")
+    x, dts, u, v, p, V = ts(T0.clone(), None, None, yc.clone(), nd[0], nd[1], nd[2], raq, fkt, fkp, xc.clone(), yc.clone(),
+                            u_prev=up.clone(), v_prev=vp.clone(), dt=dt.clone())
+    assert p is None and len(dts) == 0
+    smp = lambda t: fields.strided_sample(t.numpy(), 4001)  # noqa: E731
+    npz("g20_ts_rollout_unet", T1=smp(x[1]), T2=smp(x[2]), T3=x[3], u=smp(u), v=smp(v), V=smp(V),
+        nd=np.array([0.25, 0.26, 0.74]), paras=np.array([2.5, 1e7, 30.0]), dt=np.array(3e-5))
+
+
 # ------------------------------------------------------------------ G16 BoundaryLearnedConvolution2D (SURVEY 8f N4)
 def g16():
     for tag, (c_i, c_o, k, symm, H, W) in {"k5_symm": (8, 16, 5, True, 23, 37), "k3_plain": (16, 8, 3, False, 19, 21)}.items():
@@ -609,10 +637,66 @@ def g18():
     npz("g18_newad_dataset", **out)
 
 
+# ------------------------------------------------------------------ G19 ADTimeDataset on shard files in the reference's layout
+def g19():
+    """The reference's `datasetio.ADTimeDataset` (datasetio.py:63-280) on a tiny data directory in its file layout (full
+    series e1_{u,v,p,T}prev_data.pt, the debug mode's *_select_init.pt, times / xc / yc / sims).  `__getitem__` draws a random
+    initial-condition pair when idx0 % 8 == 0: the python RNG is seeded per item, here and in the test."""
+    import random
+    import tempfile
+    import datasetio as D
+    H, W, M = 8, 12, 11
+    g = torch.Generator().manual_seed(190)
+    sims = [(2, "train", 3.5, 2e7, 20.0, 0.0, 4.0, 0), (4, "train", 7.0, 4e8, 5.0, 0.0, 4.0, 0), (9, "cv", 1.0, 1e9, 60.0, 0.0, 4.0, 0)]
+    root = tempfile.mkdtemp()
+    torch.save(sims, root + "/sims.pt")
+    yy, xx = torch.meshgrid(torch.linspace(0.03, 0.96, H, dtype=f64), torch.linspace(0.04, 3.95, W, dtype=f64), indexing="ij")
+    out = {}
+    for num, an, *_ in sims:
+        d = f"{root}/{an}/sim_{num}"
+        os.makedirs(d)
+        content = {"times": torch.cumsum(torch.rand(M, generator=g, dtype=f64) * 1e-4, 0), "xc": xx.clone(), "yc": yy.clone()}
+        for suf, m in (("", M), ("_select_init", 3)):
+            for k in "uvpT":
+                amp = {"u": 300.0, "v": 200.0, "p": 1.0, "T": 0.5}[k]
+                content[f"e1_{k}prev_data{suf}"] = torch.rand((m, 1, H, W), generator=g, dtype=torch.float32).to(f64) * amp
+        for k, v in content.items():
+            torch.save(v, f"{d}/{k}.pt")
+            out[f"file/{an}/sim_{num}/{k}"] = v
+    out["sims_num"] = np.array([s_[0] for s_ in sims]); out["sims_an"] = np.array([s_[1] for s_ in sims])
+    out["sims_par"] = np.array([[s_[2], s_[3], s_[4], s_[5], s_[6], s_[7]] for s_ in sims])
+    t2 = out["file/train/sim_2/times"].tolist()
+    t4 = out["file/train/sim_4/times"].tolist()
+    cases = {
+        "all": dict(an="train", p_pred=True, debug=False, sims_vec=[], times_vec=[], roll_forward=1),
+        "roll2": dict(an="train", p_pred=False, debug=False, sims_vec=[], times_vec=[], roll_forward=2),
+        "debug": dict(an="cv", p_pred=False, debug=True, sims_vec=[], times_vec=[], roll_forward=1),
+        "filtered": dict(an="train", p_pred=True, debug=False, sims_vec=[2, 2, 2, 4, 4], times_vec=[t2[0], t2[3], t2[4], t4[0], t4[7]],
+                         roll_forward=1),
+    }
+    for name, kw in cases.items():
+        ds = D.ADTimeDataset(root, scale=True, load=False, noise=0.0, **kw)
+        out[f"{name}/n"] = len(ds)
+        out[f"{name}/indices"] = np.array(ds.indices).reshape(-1, 2)
+        out[f"{name}/indices_init"] = np.array(ds.indices_init).reshape(-1, 2)
+        items = []
+        for i in range(len(ds)):
+            random.seed(1000 + i)
+            items.append(ds[i])
+        out[f"{name}/x"] = torch.stack([it[0] for it in items])
+        out[f"{name}/y"] = torch.stack([it[1] for it in items])
+        out[f"{name}/s"] = torch.stack([torch.as_tensor(it[2]).reshape(()) for it in items])
+        out[f"{name}/paras"] = torch.stack([it[3].reshape(3) for it in items])
+        out[f"{name}/yc"] = items[0][4]
+        if name == "filtered":
+            out["filtered/sims_vec"] = np.array(kw["sims_vec"]); out["filtered/times_vec"] = np.array(kw["times_vec"])
+    npz("g19_adtime_dataset", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20):
         if not only or fn.__name__ in only:
             fn()
