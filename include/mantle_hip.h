@@ -66,6 +66,10 @@ typedef struct {
   int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
   int32_t out_f32;    /* dtype == MC_BF16 only: write y0 as f32 CB8 (the network's last conv: u,v,p,T are not
                          quantised to bf16); requires c_out <= 16 and no split */
+  int32_t w_rep_ci;   /* forward filter bank only, 0 = off.  Split-precision sources ("mixed" mode): the launch sees     */
+  int32_t w_rep_cs;   /* c_in0 + c_in1 channels but the filter tensor has w_rep_ci; the LAST w_rep_cs channels of the    */
+                      /* launch (the lo tensor) repeat the filter's last w_rep_cs channels, launch channels in           */
+                      /* [w_rep_ci, c_in0 + c_in1 - w_rep_cs) (padding of a narrow source) get zero filters              */
 } mc_conv_desc;
 
 typedef struct {

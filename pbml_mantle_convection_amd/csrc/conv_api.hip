@@ -56,7 +56,7 @@ __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, 
 
 // ---- batched packing: the job table travels by value in the kernel arguments (<= PK_MAX jobs per launch)
 struct PkJob {
-  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP;
+  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP, rep_ci, rep_cs;
   int dgrad, steps, ntiles, bf16, rr, first_block;
   unsigned total;
   const float* w;
@@ -210,6 +210,7 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!w_unique || !packed) return MC_EINVAL;
+  if (dgrad) g.rep_ci = g.rep_cs = 0;                       // (the filter repeat describes the forward bank only)
   if (bank_is_rr(g, dgrad)) return mc_rr_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   if (g.dtype == MC_BF16) return mc_bf16_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   size_t total = mc_packed_weight_bytes(d, dgrad) / sizeof(float);
@@ -360,6 +361,7 @@ int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_uni
       PkJob& j = t.j[k];
       j.K = g.K; j.Cout = g.Cout; j.CBin = g.CBin; j.CB0 = g.CB0; j.Cin0 = g.Cin0; j.Cin1 = g.Cin1; j.Cin = g.Cin; j.U = g.U;
       j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = g.dtype == MC_BF16;
+      j.rep_ci = j.dgrad ? 0 : g.rep_ci; j.rep_cs = j.dgrad ? 0 : g.rep_cs;
       j.rr = bank_is_rr(g, j.dgrad);
       size_t total;
       if (j.rr) {

@@ -14,6 +14,7 @@ struct ConvGeom {
   int sym_h, U;             // mirrored filters / unique filters
   int dtype;
   int out_f32;
+  int rep_ci, rep_cs;       // forward bank: filter tensor has rep_ci channels, the last rep_cs launch channels repeat its last rep_cs
 };
 
 // Device-side view of mc_conv_prologue / mc_conv_epilogue (include/mantle_hip.h): what a conv launch fuses on its input
@@ -85,6 +86,9 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.sym_h = d->sym_h; g.U = d->c_out - d->sym_h / 2;
   g.dtype = d->dtype;
   g.out_f32 = (d->dtype == MC_BF16) ? d->out_f32 : 0;
+  g.rep_ci = d->w_rep_ci; g.rep_cs = d->w_rep_cs;
+  if (g.rep_cs < 0 || g.rep_ci < 0 || (g.rep_cs > 0 && (g.rep_cs > g.rep_ci || g.rep_ci + g.rep_cs > g.Cin || g.sym_h < 0)))
+    return MC_EINVAL;
   if (g.out_f32 && (d->c_out > 16 || d->c_out_split != 0)) return MC_EUNSUPPORTED;
   // number of partial slabs of the filter-gradient reduction: enough workgroups to fill the chip
   // (~1024 with the other grid dimensions), bounded by 64 MiB of partials and by the work available
@@ -119,7 +123,7 @@ static __host__ __device__ inline int cin_padded_index(int ci, int Cin0, int CB0
 
 // ------------------------------------------------------------------------------------------------
 // filter-bank element generators shared by the single-layer and the batched pack kernels.
-// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP.
+// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP, rep_ci, rep_cs.
 // ------------------------------------------------------------------------------------------------
 template <typename G>
 __device__ __forceinline__ float bank_source(const G& g, const float* __restrict__ wu, int co, int cip, int ky, int kx) {
@@ -128,9 +132,16 @@ __device__ __forceinline__ float bank_source(const G& g, const float* __restrict
   bool ok = co < g.Cout && ob < g.CBin && (ob < g.CB0 ? (ob * 8 + oj < g.Cin0) : ((ob - g.CB0) * 8 + oj < g.Cin1));
   if (!ok) return 0.f;
   int ci = ob < g.CB0 ? ob * 8 + oj : g.Cin0 + (ob - g.CB0) * 8 + oj;
+  int cw = g.Cin;
+  if (g.rep_cs > 0) {                                          // split-precision sources: see mc_conv_desc.w_rep_ci
+    cw = g.rep_ci;
+    const int first_rep = g.Cin - g.rep_cs;
+    if (ci >= first_rep) ci = g.rep_ci - g.rep_cs + (ci - first_rep);
+    else if (ci >= g.rep_ci) return 0.f;
+  }
   int u = co, kxs = kx;
   if (co >= g.U) { u = co - g.U; kxs = g.K - 1 - kx; }        // x-mirrored copy (symmetric_layers_torch.py:121-123)
-  return wu[(((size_t)u * g.Cin + ci) * g.K + ky) * g.K + kxs];
+  return wu[(((size_t)u * cw + ci) * g.K + ky) * g.K + kxs];
 }
 
 // f32 bank [cbin][tap][ci8][CoutP] (dgrad: [cb over C_out][tap][j][CinP], rotated taps)

@@ -510,21 +510,21 @@ class Engine:
                 # forward reads (hi, lo) as a two-source concat with the filters repeated; the gradients use `desc`
                 cs = srcs[-1].C
                 c0 = ((cs + 7) // 8) * 8 if len(srcs) == 1 else srcs[0].C + cs        # channels of source 0 of the launch
+                rep = (cin_tot, cs)          # mc_conv_desc.w_rep_ci / w_rep_cs: the bank packer repeats the filters of the split source
                 e["fdesc"] = L.ConvDesc(N, h, w, c0, cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h, 0,
-                                        int(final_f32 or split_out))
-                e["fbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(e["fdesc"]), 0), dtype=torch.uint8, device=device)
-                e["w2"] = None               # [U, c0 + cs, k, k] f32, allocated at the first pack (needs the parameter's shape)
+                                        int(final_f32 or split_out), *rep)
                 if len(srcs) == 2:
                     # [plain ++ hi] ++ lo: the row-reuse kernel takes source 1 in two tensors (x1 = hi, x1b = lo; bank channel
                     # order plain, hi, lo); any other kernel family gets [plain ++ hi] materialised as one tensor
-                    fd3 = L.ConvDesc(N, h, w, srcs[0].C, 2 * cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h,
-                                     0, int(final_f32 or split_out))
                     # (A/B on MI355X: -0.2 ms per step against the materialised concat; MANTLE_X1B=0 selects the latter)
+                    fd3 = L.ConvDesc(N, h, w, srcs[0].C, 2 * cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h,
+                                     0, int(final_f32 or split_out), *rep)
                     if (os.environ.get("MANTLE_X1B", "1") != "0"
                             and L.load().mc_conv_kernel_name(C.byref(fd3)).decode().startswith("k_conv_rr")):
                         e["fdesc"], e["x1b"] = fd3, True
                     else:
                         e["cat0"] = cb8(c0, h, w)
+                e["fbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(e["fdesc"]), 0), dtype=torch.uint8, device=device)
             fusable = all(c.kind == "up" or (c.kind == "conv" and not c.learned) for c in cons[node.out])
             o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1)
                            and ho * wo <= self.fuse_maxpix and not split_out)
@@ -1027,16 +1027,8 @@ class Engine:
         jobs = []
         for e in self.convs:
             w = self._param(params, e["node"].name + "weight")
-            if "fdesc" in e:
-                fd = e["fdesc"]
-                ci = w.shape[1]
-                tot = fd.c_in0 + fd.c_in1                # channels the launch sees: [sources ..., lo of the last source]
-                cs = fd.c_in1 // 2 if e.get("x1b") else fd.c_in1      # the last cs input channels are the split source
-                if e["w2"] is None:
-                    e["w2"] = torch.zeros((w.shape[0], tot, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
-                e["w2"][:, :ci].copy_(w)                 # (channels ci .. tot - cs stay zero: padding of a lone 10-channel input)
-                e["w2"][:, tot - cs:].copy_(w[:, ci - cs:])
-                jobs.append((fd, L.ptr(e["w2"]), 0, L.ptr(e["fbank"])))
+            if "fdesc" in e:            # split-precision sources: the packer repeats the filters of the split source (w_rep_*)
+                jobs.append((e["fdesc"], L.ptr(w), 0, L.ptr(e["fbank"])))
             else:
                 jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))
             if e["need_dgrad"]:

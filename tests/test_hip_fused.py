@@ -289,10 +289,10 @@ def test_source_one_in_two_tensors_matches_the_materialised_concat(hw):
     bias = torch.randn(CO, generator=g).to(DEV)
     st = L.stream()
 
-    def run(desc, x0, x1, pro):
+    def run(desc, x0, x1, pro, wt=None):
         assert L.call("mc_conv_tiles", C.byref(desc)) > 0
         bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(desc), 0), dtype=torch.uint8, device=DEV)
-        L.call("mc_pack_weights", C.byref(desc), L.ptr(w2), 0, L.ptr(bank), st)
+        L.call("mc_pack_weights", C.byref(desc), L.ptr(w2 if wt is None else wt), 0, L.ptr(bank), st)
         y = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.float32, device=DEV)
         L.call("mc_conv2d_fused", C.byref(desc), L.ptr(x0), L.ptr(x1), pro, L.ptr(bank), L.ptr(bias), L.ptr(y), None, None, None, st)
         torch.cuda.synchronize()
@@ -306,6 +306,16 @@ def test_source_one_in_two_tensors_matches_the_materialised_concat(hw):
     d2 = L.ConvDesc(N, H, W, C0 + CS, CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
     y2 = run(d2, cat0, lo, None)
     assert torch.equal(y3, y2)
+    # the bank packer repeats the split source's filters itself (mc_conv_desc.w_rep_ci / w_rep_cs): same result from the
+    # network's own 32-channel filter tensor, single launches and the batched packer alike
+    d3r = L.ConvDesc(N, H, W, C0, 2 * CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1, C0 + CS, CS)
+    assert torch.equal(run(d3r, up, hi, C.byref(pro), wt=w), y3)
+    bank_a = torch.zeros(L.call("mc_packed_weight_bytes", C.byref(d3r), 0), dtype=torch.uint8, device=DEV)
+    bank_b = torch.zeros_like(bank_a)
+    L.call("mc_pack_weights", C.byref(d3), L.ptr(w2), 0, L.ptr(bank_a), st)
+    L.call("mc_pack_weights_batched", (L.ConvDesc * 1)(d3r), (C.c_void_p * 1)(L.ptr(w)), (C.c_int32 * 1)(0), (C.c_void_p * 1)(L.ptr(bank_b)), 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(bank_a, bank_b)
     # and against fp64 on the same (hi + lo) operand: the pair carries a to ~2^-17
     ref = torch.nn.functional.conv2d(torch.nn.functional.pad(torch.cat([_from_cb8(up, C0), hi_f + _from_cb8(lo, CS)], 1).double(),
                                                              (2, 2, 2, 2), mode="reflect"),
