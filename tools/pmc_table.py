@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
-            if "mfma" not in k and "wgrad" not in k and "gn_" not in k and "bicubic" not in k:
+            if "mfma" not in k and "conv_rr" not in k and "wgrad" not in k and "gn_" not in k and "bicubic" not in k:
                 continue
             print(k)
             for c, v in cs.items():
