@@ -200,8 +200,8 @@ def main():
     # ---- roofline of the dominant kernel: an instrumented pass of the same steps, HIP events around every
     #      launch of the conv forward/input-gradient kernel family on the launch stream
     eng = model.engine()
-    probe = eng.enable_probe()
     nprobe = min(steps, 3)
+    probe = eng.enable_probe(nprobe)
     for _ in range(nprobe):
         tr._fwd_bwd(gVTp, uvp, yc, paras, scaler, train=True)
     torch.cuda.synchronize(dev)

@@ -1045,24 +1045,34 @@ class Engine:
     # -------------------------------------------------------------- measurement hooks (bench.py)
     _probe = None
 
-    def enable_probe(self):
-        """Record a HIP-event pair (on the launch stream) around every mc_conv2d launch."""
+    def enable_probe(self, passes: int = 3):
+        """Record a HIP-event pair (on the launch stream) around every mc_conv2d launch.  The timing events are created and
+        recorded once up front: creating them lazily stalled the host for ~80 ms when the runtime grew its signal pool in the
+        middle of a pass, and that stall landed inside one event pair (round 2: a 7 ms "launch" of a 50 us kernel)."""
         self._probe = []
+        n = 2 * (2 * len(getattr(self, "convs", [])) + 8) * max(passes, 1)
+        self._probe_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for ev in self._probe_pool:
+            ev.record()
+        torch.cuda.synchronize()
         return self._probe
 
     def disable_probe(self):
         self._probe = None
+        self._probe_pool = []
+
+    def _probe_event(self):
+        ev = self._probe_pool.pop() if getattr(self, "_probe_pool", None) else torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     def _probe_begin(self):
         if self._probe is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            self._probe_ev = ev
+            self._probe_ev = self._probe_event()
 
     def _probe_end(self, d, label):
         if self._probe is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
+            ev = self._probe_event()
             es = torch.tensor([], dtype=self.t_dtype).element_size()
             ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
             cin = d.c_in0 + d.c_in1
