@@ -105,6 +105,12 @@ def test_unet_bf16_forward_vs_quantised_oracle(golden, tag):
     assert rel_l2(y, ref) < 1.5e-2, rel_l2(y, ref)
 
 
+# measured on MI355X (round 2): whole-gradient rel-L2 0.014 / 0.015 / 0.015 (mae, mass_rep, mae_zeros), 0.095 (curl: the head takes
+# one-pixel differences x 126 of a bf16-noisy streamfunction); worst single tensor 0.065 / 0.071 / 0.050, curl 0.31
+WHOLE_BOUND = {"curl": 0.15, "mae": 0.03, "mass_rep": 0.03, "mae_zeros": 0.03}
+WORST_BOUND = {"curl": 0.45, "mae": 0.12, "mass_rep": 0.12, "mae_zeros": 0.12}
+
+
 @pytest.mark.parametrize("tag", ["curl", "mae", "mass_rep", "mae_zeros"])
 def test_unet_bf16_vs_golden(golden, tag):
     from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
@@ -123,9 +129,18 @@ def test_unet_bf16_vs_golden(golden, tag):
         assert float(np.abs(o.detach().double().cpu().numpy() - ref).mean()) <= 0.12 * float(np.abs(ref).mean()), n
         loss = loss + (o * dev(g["ct/" + n])).sum()
     loss.backward()
-    worst = max(rel_l2(p.grad, g["grad/" + n]) for n, p in m.named_parameters()
-                if float(np.abs(g["grad/" + n]).max()) > 1e-6)
-    assert worst < 0.45, worst
+    named = [(n, p) for n, p in m.named_parameters() if float(np.abs(g["grad/" + n]).max()) > 1e-6]
+    worst = max(rel_l2(p.grad, g["grad/" + n]) for n, p in named)
+    num = sum(float((p.grad.double().cpu() - torch.from_numpy(g["grad/" + n])).norm() ** 2) for n, p in named)
+    den = sum(float(np.linalg.norm(g["grad/" + n]) ** 2) for n, p in named)
+    whole = (num / den) ** 0.5
+    print(f"\n[{tag}] bf16 vs fp64 golden: whole-gradient rel-L2 {whole:.3f}, worst tensor {worst:.3f}")
+    # Two bounds.  The gradient as a whole (the direction an optimizer step takes) carries the bf16 noise of a 14-layer
+    # network on a 40 x 54 image; single small tensors (GroupNorm offsets whose true gradient nearly cancels over 2000
+    # pixels) are far noisier.  At the benched size the same quantities are 6 x smaller: whole 0.033, worst 0.071
+    # (tests/test_hip_fullsize.py::test_cfg3_training_step_506_bf16_gradients_vs_oracle, bounds 0.10 / 0.15).
+    assert whole < WHOLE_BOUND[tag], whole
+    assert worst < WORST_BOUND[tag], worst
 
 
 @pytest.mark.parametrize("tag", ["mae", "curl"])
@@ -146,6 +161,9 @@ def test_convae_bf16_vs_golden(golden, tag):
     num = sum(float((p.grad.double().cpu() - torch.from_numpy(g["grad/" + n])).norm() ** 2) for n, p in m.named_parameters())
     den = sum(float(np.linalg.norm(g["grad/" + n]) ** 2) for n, _ in m.named_parameters())
     assert (num / den) ** 0.5 < 0.2, (num / den) ** 0.5
+
+
+TRAIN_WHOLE_BOUND, TRAIN_WORST_BOUND = 0.06, 0.15          # measured 0.037 / 0.099
 
 
 @pytest.mark.parametrize("tag", ["mass", "curl"])
@@ -179,8 +197,13 @@ def test_training_steps_bf16_vs_golden(golden, tag):
             assert abs(vals[0] - ref[0]) <= 5e-2 * abs(ref[0]), (vals, ref)
         if step == 0 and tag != "curl":       # curl + loss_derivative: sign(noise-level differences) dominates the gradient
             grads = tr.flat.views(tr.flat.grad)
-            worst = max(rel_l2(grads[n], g["grad0/" + n]) for n in grads if float(np.abs(g["grad0/" + n]).max()) > 1e-6)
-            assert worst < 0.45, worst
+            names = [n for n in grads if float(np.abs(g["grad0/" + n]).max()) > 1e-6]
+            worst = max(rel_l2(grads[n], g["grad0/" + n]) for n in names)
+            num = sum(float((grads[n].double().cpu() - torch.from_numpy(g["grad0/" + n])).norm() ** 2) for n in names)
+            den = sum(float(np.linalg.norm(g["grad0/" + n]) ** 2) for n in names)
+            print(f"\n[train {tag}] bf16 vs fp64 golden at 128 x 506: whole-gradient rel-L2 {(num / den) ** 0.5:.3f}, worst tensor {worst:.3f}")
+            assert (num / den) ** 0.5 < TRAIN_WHOLE_BOUND, (num / den) ** 0.5
+            assert worst < TRAIN_WORST_BOUND, worst
 
 
 @pytest.mark.parametrize("dtype_name", ["bf16", "fp32"])
