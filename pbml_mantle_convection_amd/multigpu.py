@@ -264,13 +264,16 @@ class Trainer:
                 self._fwd_bwd(st["gVTp"], st["uvp"], st["yc"], st["paras"], st["scaler"], train=True)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(self.device)
+            # with a process group alive its watchdog thread polls events while we capture: only calls of THIS thread may
+            # invalidate the capture (the default "global" mode would turn the watchdog's event query into a capture error)
+            mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, **mode):
                 self._static_out = self._fwd_bwd(st["gVTp"], st["uvp"], st["yc"], st["paras"], st["scaler"],
                                                  train=True)
             # Adam is a graph of its own: for world > 1 the flat-gradient all-reduce runs between the two replays
             self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt):
+            with torch.cuda.graph(self._graph_opt, **mode):
                 self._optim_step()
             # the graph holds the engine's and the loss's device pointers: pin their shapes (another batch size through
             # eval_step / get_loss / model(x) would otherwise re-plan them and the next replay would touch freed memory)

@@ -53,3 +53,25 @@ def run(rank, world, port, prec, nsteps, outdir):
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_rccl_single(port, outdir):
+    """One rank, backend 'nccl' (= RCCL): the process group and its watchdog thread are alive while the training step is
+    captured and replayed, and the flat buffers go through RCCL's broadcast / all-reduce entry points once."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from pbml_mantle_convection_amd import multigpu as G
+    G.ddp_setup(0, 1, port, backend="nccl")
+    assert dist.get_backend() == "nccl"
+    tr = make_trainer("bf16", 100)
+    res = steps(tr, global_batch(), 3)
+    t = tr.flat.grad.clone()
+    dist.all_reduce(t)                                   # RCCL on the flat gradient buffer (world 1: identity)
+    dist.broadcast(tr.flat.param, src=0)
+    torch.cuda.synchronize()
+    assert torch.equal(t, tr.flat.grad)
+    np.savez(os.path.join(outdir, "rccl1.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -52,3 +52,21 @@ def test_two_ranks_match_each_other_and_the_single_process_step(prec, tmp_path):
     # Adam's first steps move every weight by ~lr whatever |g| is, so an entry whose gradient is ~0 may differ by up to lr
     assert (d > 0.1 * lr).mean() <= (2e-3 if prec == "fp32" else 1e-2), (d > 0.1 * lr).mean()
     assert d.max() <= 2.5 * nsteps * lr
+
+
+def test_captured_step_with_a_live_rccl_process_group(tmp_path):
+    """backend='nccl' with ONE rank (all this box has): RCCL initialises, its watchdog thread runs while the step is captured
+    (capture_error_mode='thread_local') and replayed, all-reduce / broadcast of the flat buffers go through RCCL; the result
+    equals the run without a process group.  (Two ranks over RCCL need two GPUs: unverified here)"""
+    import ddp_worker as W
+    ctx = mp.get_context("forkserver")
+    p = ctx.Process(target=W.run_rccl_single, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(300)
+    if p.is_alive():
+        p.terminate()
+    assert p.exitcode == 0, p.exitcode
+    r = np.load(tmp_path / "rccl1.npz")
+    one = W.steps(W.make_trainer("bf16", 100), W.global_batch(), 3)
+    for k in ("grad1", "param", "m", "v"):
+        assert np.array_equal(r[k], one[k]), k
