@@ -279,6 +279,11 @@ int mc_bicubic_bwd(const mc_grad_src* g, int32_t n, int32_t c, int32_t hi, int32
                    const int32_t* ty_start, const int32_t* ty_j, const float* ty_w,
                    const int32_t* tx_start, const int32_t* tx_j, const float* tx_w,
                    int32_t dtype, void* dx, void* stream);
+/* The same with the longest tap list of each table given (host knowledge of the tables; 0 = unknown): lists of <= 8 entries
+ * (every even x2 upsample) run a kernel instantiation that holds 8 instead of 12 taps per pixel on chip. */
+int mc_bicubic_bwd_taps(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                        const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
+                        const float* txw, int32_t max_taps_y, int32_t max_taps_x, int32_t dtype, void* dx, void* stream);
 /* The same adjoint as two 1-D passes through an f32 workspace [n][ceil(c/8)][hi][wo][8]: for large scale factors
  * (NewFluidNet upsamples x4 ... x16 to the full grid, pytorch_networks_convae.py:1239-1244), where a pixel's tap lists
  * are too long for the tiled kernel. */

@@ -99,6 +99,8 @@ SIGNATURES = {
     "mc_bicubic_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mc_bicubic_bwd": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                  _vp, _vp]),
+    "mc_bicubic_bwd_taps": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                      _vp, _vp]),
     "mc_bicubic_bwd_separable": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                            _vp, _vp, _vp]),
     "mc_curl_head_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),

@@ -889,14 +889,15 @@ __global__ __launch_bounds__(256) void k_bicubic_fwd(const T* __restrict__ x, in
 // y with the transposed tap lists (lanes run over window columns: conflict-free), then along x from a planar f32
 // intermediate.  Pixels whose lists leave the window (image borders of large scale factors) gather from global memory.
 constexpr int BT = 16, BWIN = 40;
-template <typename T>
+// BYT / BXT: tap-list lengths held on chip (8 covers every list of an even x2 upsample, 12 the odd sizes; longer lists take
+// the per-pixel gather path).  With 12 slots for 8-entry lists a third of both passes multiplied zeros (331 us at level 0).
+template <typename T, int BYT, int BXT>
 __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int Hi, int Wi, const int* __restrict__ tys,
                                                      const int* __restrict__ tyj, const float* __restrict__ tyw,
                                                      const int* __restrict__ txs, const int* __restrict__ txj,
                                                      const float* __restrict__ txw, T* __restrict__ dx, int tiles_x) {
   __shared__ __attribute__((aligned(16))) T win[BWIN * BWIN * 8];
   __shared__ float4 tmp[2][BT][BWIN];
-  constexpr int BYT = 12, BXT = 12;                        // tap-list lengths held on chip (longer lists: slow path)
   __shared__ int s_yj[BT][BYT];
   __shared__ float s_yw[BT][BYT];
   const int n = blockIdx.z, cb = blockIdx.y;
@@ -1595,9 +1596,9 @@ int mc_bicubic_fwd(const void* x, int32_t n, int32_t c, int32_t hi, int32_t wi, 
   return mc_bicubic_fwd_act(x, nullptr, MC_ACT_NONE, n, c, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, dtype, out, stream);
 }
 
-int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
-                   const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
-                   const float* txw, int32_t dtype, void* dx, void* stream) {
+int mc_bicubic_bwd_taps(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                        const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
+                        const float* txw, int32_t max_taps_y, int32_t max_taps_x, int32_t dtype, void* dx, void* stream) {
   if (!gs || !dx || !tys || !tyj || !tyw || !txs || !txj || !txw || n <= 0 || c <= 0) return MC_EINVAL;
   int rc = check_gsrc(gs);
   if (rc) return rc;
@@ -1607,11 +1608,22 @@ int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int3
   int tiles_x = cdiv(wi, BT), tiles_y = cdiv(hi, BT);
   dim3 g(tiles_x * tiles_y, C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_bwd<float>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (float*)dx, tiles_x);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_bwd<bf16_t>, g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (bf16_t*)dx, tiles_x);
+  const bool y8 = max_taps_y > 0 && max_taps_y <= 8, x8 = max_taps_x > 0 && max_taps_x <= 8;
+#define BW(T, A, B) hipLaunchKernelGGL((k_bicubic_bwd<T, A, B>), g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (T*)dx, tiles_x)
+#define BWT(T) do { if (y8 && x8) BW(T, 8, 8); else if (y8) BW(T, 8, 12); else if (x8) BW(T, 12, 8); else BW(T, 12, 12); } while (0)
+  if (dtype == MC_F32) BWT(float);
+  else if (dtype == MC_BF16) BWT(bf16_t);
   else return MC_EUNSUPPORTED;
+#undef BWT
+#undef BW
   MC_CHECK_LAUNCH();
   return MC_OK;
+}
+
+int mc_bicubic_bwd(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                   const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
+                   const float* txw, int32_t dtype, void* dx, void* stream) {
+  return mc_bicubic_bwd_taps(gs, n, c, hi, wi, ho, wo, tys, tyj, tyw, txs, txj, txw, 0, 0, dtype, dx, stream);
 }
 
 int mc_bicubic_bwd_separable(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,

@@ -439,7 +439,8 @@ class Engine:
                 o.H, o.W = ho, wo
                 o.buf = cb8(o.C, ho, wo)
                 tabs = (self._table(s.H, ho), self._table(s.W, wo))
-                e = dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W))
+                e = dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W),
+                         maxtaps=tuple(int(np.diff(bicubic_tables(a, b)[2]).max()) for a, b in ((s.H, ho), (s.W, wo))))
                 if ho > 3 * s.H or wo > 3 * s.W:
                     # scale factor > 3: the adjoint runs as two 1-D passes through an f32 workspace (tap lists too long
                     # for the tiled kernel's window)
@@ -911,8 +912,9 @@ class Engine:
                     L.call("mc_bicubic_bwd_separable", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
                            L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["bws"]), L.ptr(e["dsrc"]), st)
                 else:
-                    L.call("mc_bicubic_bwd", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
-                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["dsrc"]), st)
+                    L.call("mc_bicubic_bwd_taps", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
+                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), e["maxtaps"][0], e["maxtaps"][1], self.mc_dtype,
+                           L.ptr(e["dsrc"]), st)
                 s.gsrcs.append(L.GradSrc(L.ptr(e["dsrc"]), L.GSRC_PLAIN, 0, 0, 1, s.H, s.W))
                 continue
             d = e["desc"]
