@@ -338,3 +338,33 @@ def test_source_one_in_two_tensors_matches_the_materialised_concat(hw):
     act = torch.nn.functional.gelu(_from_cb8(yf, CS).double())
     assert float((_from_cb8(h_, CS).double() + _from_cb8(l_, CS).double() - act).abs().max()) <= 3e-4
     assert torch.equal(yb, yf.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("kind", ["unet", "unet16", "convae", "newfluidnet"])
+def test_mixed_precision_mode_on_every_graph(kind):
+    """precision='mixed' (split-precision full-resolution level) on graphs with pooled / concatenated / upsampled consumers of
+    the split tensors (they read the hi part): forward and every parameter gradient stay as close to the fp32 execution as the
+    plain bf16 mode is (the split can only remove rounding), and the U-Net output gets closer."""
+    from pbml_mantle_convection_amd.pytorch_networks_convae import NewFluidNet
+    res = {}
+    for prec in ("fp32", "bf16", "mixed"):
+        if kind == "newfluidnet":
+            torch.manual_seed(11)
+            m = NewFluidNet(3, 7, 16, 3, torch.device(DEV), "gelu", "zeros", "mae", use_symm=True, repeats=2, f=5, p_pred=True)
+            shape = (2, 7, 64, 90)
+        else:
+            m, shape = _build(kind, "reflect", 11)
+        m = m.to(DEV).set_precision(prec)
+        g = torch.Generator().manual_seed(12)
+        x = torch.randn(shape, generator=g).to(DEV)
+        outs = m(x)
+        outs = [o for o in (outs if isinstance(outs, (tuple, list)) else [outs]) if o is not None]
+        loss = sum((o * torch.randn(o.shape, generator=g).to(DEV)).sum() for o in outs)
+        loss.backward()
+        res[prec] = (torch.cat([o.detach().flatten() for o in outs]), torch.cat([p.grad.flatten() for p in m.parameters()]))
+    for j, what in enumerate(("output", "gradient")):
+        e_bf = rel_l2(res["bf16"][j], res["fp32"][j])
+        e_mx = rel_l2(res["mixed"][j], res["fp32"][j])
+        assert e_mx <= 1.25 * e_bf + 1e-3, (kind, what, e_mx, e_bf)
+    if kind.startswith("unet"):
+        assert rel_l2(res["mixed"][0], res["fp32"][0]) < rel_l2(res["bf16"][0], res["fp32"][0])
