@@ -4,6 +4,7 @@
 // tile-local reduction with a deterministic two-stage combine.  The bf16 MFMA path lives in
 // conv_bf16.hip and implements the same entry points for dtype == MC_BF16.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -65,23 +66,30 @@ __global__ __launch_bounds__(256) void k_conv_direct_f32(ConvGeom g, const float
     }
     __syncthreads();
     const float* wb = bank + (size_t)cb * K * K * 8 * g.CoutP + co0;
-    // the last channel group of a bank whose CoutP is not a multiple of 16 has only 8 columns: clamp the column so the
-    // (unused) upper accumulators never read past the end of the bank
+    // The 16 filter values of a (tap, input channel) are consecutive: with constant offsets the compiler merges their scalar
+    // loads (s_load_dwordx16).  Only the last channel group of a bank whose CoutP is not a multiple of 16 has 8 columns: that
+    // block takes the clamped form, whose unused upper accumulators never read past the end of the bank.  (Round 2 first
+    // clamped unconditionally: sixteen separate scalar loads per channel, the f32 path ran at 15 instead of 44 TFLOP/s.)
     const int comax = g.CoutP - 1 - co0;
+    auto taps = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky)
+      for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const float* xv = xs[(ty + ky) * TI + tx + kx];
-        float4 a = *reinterpret_cast<const float4*>(xv);
-        float4 b = *reinterpret_cast<const float4*>(xv + 4);
-        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        const float* wt = wb + (size_t)(ky * K + kx) * 8 * g.CoutP;
+        for (int kx = 0; kx < K; ++kx) {
+          const float* xv = xs[(ty + ky) * TI + tx + kx];
+          float4 a = *reinterpret_cast<const float4*>(xv);
+          float4 b = *reinterpret_cast<const float4*>(xv + 4);
+          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          const float* wt = wb + (size_t)(ky * K + kx) * 8 * g.CoutP;
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci)
+          for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
-          for (int co = 0; co < 16; ++co) acc[co] = fmaf(v[ci], wt[ci * g.CoutP + min(co, comax)], acc[co]);
-      }
+            for (int co = 0; co < 16; ++co) acc[co] = fmaf(v[ci], wt[ci * g.CoutP + (FULL ? co : min(co, comax))], acc[co]);
+        }
+    };
+    if (comax >= 15) taps(std::true_type{});
+    else taps(std::false_type{});
   }
 
   const bool valid = oy < g.Ho && ox < g.Wo;
