@@ -16,7 +16,7 @@ int mc_wgrad_bf16(const ConvGeom& g, const void* x0, const void* x1, const void*
 const char* mc_bf16_kernel_name(const ConvGeom& g);
 void mc_bf16_bank_dims(const ConvGeom& g, int dgrad, int& chunks, int& steps, int& ntiles);
 // row-reuse bf16 path for single-output-tile layers (conv_rr_bf16.hip)
-bool mc_rr_applies(int dtype, int cout, int wo);
+bool mc_rr_applies(int dtype, int cout, int wo, bool full_pad);
 size_t mc_rr_bank_bytes(const ConvGeom& g, int dgrad);
 int mc_rr_pack(const ConvGeom& g, const float* w_unique, int dgrad, void* packed, hipStream_t s);
 int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
@@ -28,7 +28,7 @@ namespace {
 // forward / input-gradient kernel family of a descriptor: the row-reuse kernel takes the layers with one 16-channel
 // output tile per work-group (an odd number of output tiles), the wide-tile kernel the rest
 bool rr_desc(const mc_conv_desc* d) {
-  return mc_rr_applies(d->dtype, d->c_out, d->w + 2 * d->pad - d->k + 1);
+  return mc_rr_applies(d->dtype, d->c_out, d->w + 2 * d->pad - d->k + 1, d->pad == d->k - 1);
 }
 
 int geom_for(const mc_conv_desc* d, ConvGeom& g) {
@@ -179,7 +179,7 @@ int wf_fill(const mc_conv_desc* d, const void* partials, float* dw, float* db, W
 // channels are this layer's input channels), the forward bank by this layer's own family.
 static bool bank_is_rr(const ConvGeom& g, int dgrad) {
   // (the input-gradient convolution runs on the padded domain of this layer's input: width W + 2 pad)
-  return dgrad ? mc_rr_applies(g.dtype, g.Cin, g.W + 2 * g.pad) : mc_rr_applies(g.dtype, g.Cout, g.Wo);
+  return dgrad ? mc_rr_applies(g.dtype, g.Cin, g.W + 2 * g.pad, true) : mc_rr_applies(g.dtype, g.Cout, g.Wo, g.pad == g.K - 1);
 }
 
 extern "C" {

@@ -538,11 +538,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 // MC_RR_MINW pixels wide — each output tile is then a separate work-group column (grid.y) that stages the window again,
 // which the idle loader waves absorb, and the MFMA work per stage is the same.  MC_CONV_RR=0 turns the kernel off, 1
 // restricts it to the odd case.
-bool mc_rr_applies(int dtype, int cout, int wo) {
+bool mc_rr_applies(int dtype, int cout, int wo, bool full_pad) {
   const int ntiles = (cout + 15) / 16;
   static const int on = [] { const char* e = getenv("MC_CONV_RR"); return e ? atoi(e) : 2; }();
   static const int minw = [] { const char* e = getenv("MC_RR_MINW"); return e ? atoi(e) : 48; }();
+  // launches with full padding (pad = k - 1: the input-gradient convolutions) run on a domain 2 (k - 1) pixels wider than
+  // the layer: the 64-wide tiles then waste up to a whole tile column, which the wide-tile kernel's 16 / 32-wide tiles do not
+  // (A/B on MI355X, CFG-3 step, mixed / bf16: 0: 12.16 / 10.74 ms, 140: 12.12 / 10.70, 270: 12.32 / 10.86, 520: 12.62 / 11.18)
+  static const int minw_full = [] { const char* e = getenv("MC_RR_MINW_DGRAD"); return e ? atoi(e) : 140; }();
   if (!on || dtype != MC_BF16) return false;
+  if (full_pad && minw_full > 0 && wo < minw_full) return false;
   if (ntiles % 2 == 1) return true;
   return on >= 2 && ntiles <= 8 && wo >= minw;
 }
