@@ -219,6 +219,12 @@ int mc_gn_finalize_coef(const float* stat_partials, int32_t n, int32_t tiles, in
 int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                   const float* stats_ng2, const float* gamma, const float* beta, int32_t post,
                   int32_t act, int32_t pool, int32_t dtype, void* a, void* pooled, void* stream);
+/* Small layers: mc_gn_finalize + mc_gn_act_fwd in one launch (one block per (sample, channel block); c / groups in
+ * {1, 2, 4, 8}; pool 1 or 2): statistics from the conv's stat_partials [n][tiles][c8*8][2], written to stats_ng2 for the
+ * backward pass, and a = act(GN(y)) [+ AvgPool2d(pool)]. */
+int mc_gn_act_fwd_small(const void* y, const float* stat_partials, int32_t tiles, int32_t n, int32_t c, int32_t h, int32_t w,
+                        int32_t groups, float eps, const float* gamma, const float* beta, int32_t act, int32_t pool,
+                        int32_t dtype, float* stats_ng2, void* a, void* pooled, void* stream);
 /* bf16 mode, tail of the network: y is an F32 conv output (mc_conv_desc.out_f32); a = act(GN(y)) is evaluated in f32 and
  * written as two bf16 tensors a_hi = bf16(a), a_lo = bf16(a - a_hi) which the next conv reads as a two-source concat with
  * its filter bank repeated (a to ~2^-17).  y_bf16 = bf16(y) is what the backward kernels read.  Keeps the second
@@ -241,6 +247,15 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
                         const float* stats_ng2, const float* m12_ng2, const float* gamma,
                         const float* beta, int32_t post, int32_t act, int32_t dtype,
                         const mc_grad_src* g0, const mc_grad_src* g1, void* dy, void* stream);
+/* Small layers: the three phases in one launch (one block per (sample, channel block); needs c / groups in {1, 2, 4, 8}).
+ * Writes dy and the per-(sample, channel) sums chan_sums [n][ceil(c/8)*8][2] = (sum dz, sum dz * yhat); dgamma / dbeta are
+ * accumulated from those tables, samples in order, by mc_gn_param_grads_batched (one launch for many layers: per-layer
+ * tables are plain host arrays of length `jobs`). */
+int mc_gn_act_bwd_small(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats_ng2,
+                        const float* gamma, const float* beta, int32_t act, int32_t dtype, const mc_grad_src* g0,
+                        const mc_grad_src* g1, void* dy, float* chan_sums, void* stream);
+int mc_gn_param_grads_batched(const float* const* chan_sums, const int32_t* n, const int32_t* c, float* const* dgamma,
+                              float* const* dbeta, int32_t jobs, void* stream);
 /* Phase 3 for a tensor whose dz = dA * act'(z) was already written by mc_conv2d_fused's epilogue (+ mc_fold_padded_dz):
  * dy = scale * dz - rstd (m1 + yhat m2)  (coef = the layer's table, m12 from mc_gn_act_bwd_finalize); with coef == NULL
  * (activation-only layer) dy = dz.  dz is read through a gradient source (MC_GSRC_PADFOLD or MC_GSRC_PLAIN). */

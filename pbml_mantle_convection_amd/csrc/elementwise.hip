@@ -306,6 +306,76 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
   }
 }
 
+// Small layers: GroupNorm statistics from the conv's partial sums AND a = act(GN(y)) [+ AvgPool] in one launch, one block per
+// (sample, channel block); needs every group inside one channel block (channels per group 1, 2, 4 or 8).  The (mean, rstd)
+// pairs are also written out for the backward pass.  Same f64 sums and f32 expressions as k_gn_finalize / gn_coef.
+template <typename T, int POOL>
+__global__ __launch_bounds__(1024) void k_gn_act_small(GnArgs a, const T* __restrict__ y, const float* __restrict__ part, int tiles,
+                                                       float eps, float* __restrict__ stats_out, T* __restrict__ out,
+                                                       T* __restrict__ pooled) {
+  const int n = (int)blockIdx.y, cb = blockIdx.x, CP = a.C8 * 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float s_mean[8], s_rstd[8];
+  const int ng = 8 / a.cpg;                                   // groups of this channel block (some may lie beyond C)
+  if (wave < ng) {
+    const int c0 = cb * 8 + wave * a.cpg;
+    if (c0 < a.C) {
+      double cs, css;
+      group_channel_sums(part, (size_t)n * tiles, tiles, CP, c0, a.cpg, cs, css);
+      for (int o = 1; o < a.cpg; o <<= 1) { cs += __shfl_xor(cs, o, 64); css += __shfl_xor(css, o, 64); }
+      const double m = (double)a.cpg * (double)a.H * (double)a.W;
+      const double mean = cs / m;
+      double var = css / m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float meanf = (float)mean, rstdf = (float)(1.0 / sqrt(var + (double)eps));
+      if (lane == 0) {
+        s_mean[wave] = meanf; s_rstd[wave] = rstdf;
+        const int g = c0 / a.cpg;
+        stats_out[((size_t)n * a.groups + g) * 2] = meanf;
+        stats_out[((size_t)n * a.groups + g) * 2 + 1] = rstdf;
+      }
+    }
+  }
+  __syncthreads();
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j;
+    sc[j] = 0.f; sh[j] = 0.f;
+    if (c < a.C) {
+      const float mean = s_mean[j / a.cpg], rstd = s_rstd[j / a.cpg], ga = a.gamma[c], be = a.beta[c];
+      sc[j] = rstd * ga;
+      sh[j] = be - mean * rstd * ga;
+    }
+  }
+  const int Hb = (a.H + POOL - 1) / POOL, Wb = (a.W + POOL - 1) / POOL;
+  const int Hp = a.H / POOL, Wp = a.W / POOL;
+  for (int i = threadIdx.x; i < Hb * Wb; i += blockDim.x) {
+    const int by = i / Wb, bx = i - by * Wb;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < POOL; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < POOL; ++dx) {
+        const int yy = by * POOL + dy, xx = bx * POOL + dx;
+        if (yy < a.H && xx < a.W) {
+          float v[8];
+          const size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
+          V8<T>::ld(y + idx, v);
+          act_fwd8<FastMath<T>::value>(v, sc, sh, a.act, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += v[j];
+          V8<T>::st(out + idx, v);
+        }
+      }
+    if (POOL > 1 && by < Hp && bx < Wp) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= 1.0f / (POOL * POOL);
+      V8<T>::st(pooled + cb8_index(n, cb, by, bx, a.C8, Hp, Wp), acc);
+    }
+  }
+}
+
 // Split-precision activation of an f32 conv output (the tail of the network in bf16 mode): a = act(GN(y)) evaluated in f32
 // and stored as TWO bf16 tensors hi = bf16(a), lo = bf16(a - hi), so that the consuming conv -- which reads (hi, lo) as a
 // two-source concat with the filter bank repeated -- sees a to ~2^-17 instead of 2^-9.  Also writes bf16(y), which the
@@ -579,6 +649,121 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
     }
     V8<T>::st(dy + idx, o);
   }
+}
+
+// Small layers (levels >= 2 of the U-Net: <= 128 x 128 pixels): the three phases above in ONE launch.  One block per (sample,
+// channel block) walks its 8 channels x H x W twice -- sums, block reduction in a fixed order, coefficients, dy -- the second
+// walk is served by the caches.  The separate reduce / finalize / apply launches of such a layer take 40-50 us for < 1 MB of
+// data: they are bound by launch latency, not by bytes.  Needs every group inside one channel block (channels per group
+// 1, 2, 4 or 8).  The per-(sample, channel) sums go to `pc` [N][CP][2]; k_gn_param_grads adds them to dgamma / dbeta in sample
+// order for all such layers at the end of the backward pass.
+template <typename T, int GK>
+__global__ __launch_bounds__(1024) void k_gn_bwd_small(GnArgs a, const T* __restrict__ y, mc_grad_src g0, mc_grad_src g1,
+                                                       T* __restrict__ dy, float* __restrict__ pc, int CP) {
+  const int n = (int)blockIdx.y, cb = blockIdx.x;
+  float sc[8], sh[8], mean[8], rstd[8], ga[8];
+  gn_coef(a, n, cb, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j;
+    mean[j] = 0.f; rstd[j] = 0.f; ga[j] = 0.f;
+    if (c < a.C) {
+      const int g = c / a.cpg;
+      mean[j] = a.stats[((size_t)n * a.groups + g) * 2];
+      rstd[j] = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+      ga[j] = a.gamma[c];
+    }
+  }
+  const int total = a.H * a.W;
+  float s[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int yy = i / a.W, xx = i - yy * a.W;
+    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gz[8];
+    V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
+    grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
+    act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dz = da[j] * gz[j];
+      s[2 * j] += dz;
+      s[2 * j + 1] += dz * (v[j] - mean[j]) * rstd[j];
+    }
+  }
+  __shared__ float red[16][16];
+  __shared__ float tot[16];
+  {
+    int idx;
+    const float r = wave_sum16(s, threadIdx.x & 63, idx);
+    if ((threadIdx.x & 3) == 0) red[threadIdx.x >> 6][idx] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float r = 0.f;
+    const int nw = (int)blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) r += red[w][threadIdx.x];          // fixed order: deterministic
+    tot[threadIdx.x] = r;
+    const int c = cb * 8 + (threadIdx.x >> 1);
+    if (c < CP) pc[((size_t)n * CP + c) * 2 + (threadIdx.x & 1)] = r;
+  }
+  __syncthreads();
+  // m1 = sum_c gamma_c s1_c / M, m2 = sum_c gamma_c s2_c / M over the channels of the group (all inside this channel block)
+  float cA[8], cB[8], cC[8];
+  const float invM = 1.0f / ((float)a.cpg * (float)total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j;
+    float m1 = 0.f, m2 = 0.f;
+    if (c < a.C) {
+      const int j0 = (j / a.cpg) * a.cpg;
+      for (int k = 0; k < a.cpg; ++k) {
+        const float gk = a.gamma[cb * 8 + j0 + k];
+        m1 += gk * tot[2 * (j0 + k)];
+        m2 += gk * tot[2 * (j0 + k) + 1];
+      }
+      m1 *= invM; m2 *= invM;
+    }
+    cA[j] = rstd[j] * ga[j];
+    cB[j] = -rstd[j] * rstd[j] * m2;
+    cC[j] = -rstd[j] * m1;
+  }
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int yy = i / a.W, xx = i - yy * a.W;
+    float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gz[8], o[8];
+    const size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
+    V8<T>::ld(y + idx, v);
+    grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
+    grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
+    act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 dz = (f32x2){da[j], da[j + 1]} * (f32x2){gz[j], gz[j + 1]};
+      const f32x2 t = (f32x2){v[j], v[j + 1]} - (f32x2){mean[j], mean[j + 1]};
+      const f32x2 r = pk_fma((f32x2){cA[j], cA[j + 1]}, dz, pk_fma((f32x2){cB[j], cB[j + 1]}, t, (f32x2){cC[j], cC[j + 1]}));
+      o[j] = r.x; o[j + 1] = r.y;
+    }
+    V8<T>::st(dy + idx, o);
+  }
+}
+
+// dgamma[c] += sum_n pc[n][c][1], dbeta[c] += sum_n pc[n][c][0], samples in order, for up to GP_MAX layers per launch
+constexpr int GP_MAX = 32;
+struct GpJob { const float* pc; float* dgamma; float* dbeta; int N, C, CP, first; };
+struct GpTable { int n; GpJob j[GP_MAX]; };
+__global__ void k_gn_param_grads(GpTable t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int ji = 0;
+#pragma unroll 1
+  for (int k = 1; k < t.n; ++k) if (i >= t.j[k].first) ji = k;
+  const GpJob& j = t.j[ji];
+  const int c = i - j.first;
+  if (c >= j.C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < j.N; ++n) { s1 += j.pc[((size_t)n * j.CP + c) * 2]; s2 += j.pc[((size_t)n * j.CP + c) * 2 + 1]; }
+  if (j.dgamma) j.dgamma[c] += s2;
+  if (j.dbeta) j.dbeta[c] += s1;
 }
 
 // in-place adjoint of F.pad on a padded-domain gradient: one thread per border TARGET pixel (a pixel of the
@@ -1445,6 +1630,69 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
     switch (gkind_of(s0, s1)) { case 1: APP(bf16_t, 1); break; case 2: APP(bf16_t, 2); break; case 3: APP(bf16_t, 3); break; default: APP(bf16_t, 0); }
   } else return MC_EUNSUPPORTED;
 #undef APP
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_fwd_small(const void* y, const float* stat_partials, int32_t tiles, int32_t n, int32_t c, int32_t h, int32_t w,
+                        int32_t groups, float eps, const float* gamma, const float* beta, int32_t act, int32_t pool,
+                        int32_t dtype, float* stats_out, void* a_out, void* pooled, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats_out, gamma, beta, MC_POST_GN_ACT, act);
+  if (rc) return rc;
+  if (!y || !stat_partials || tiles <= 0 || !gamma || !beta || !stats_out || !a_out || (pool > 1 && !pooled)) return MC_EINVAL;
+  if (pool != 1 && pool != 2) return MC_EUNSUPPORTED;
+  if (a.cpg != 1 && a.cpg != 2 && a.cpg != 4 && a.cpg != 8) return MC_EUNSUPPORTED;
+  dim3 g(a.C8, n);
+  hipStream_t s = (hipStream_t)stream;
+#define FS(T, P) hipLaunchKernelGGL((k_gn_act_small<T, P>), g, dim3(1024), 0, s, a, (const T*)y, stat_partials, tiles, eps, stats_out, (T*)a_out, (T*)pooled)
+  if (dtype == MC_F32) { if (pool == 1) FS(float, 1); else FS(float, 2); }
+  else if (dtype == MC_BF16) { if (pool == 1) FS(bf16_t, 1); else FS(bf16_t, 2); }
+  else return MC_EUNSUPPORTED;
+#undef FS
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_bwd_small(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
+                        const float* gamma, const float* beta, int32_t act, int32_t dtype, const mc_grad_src* g0,
+                        const mc_grad_src* g1, void* dy, float* chan_sums, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, MC_POST_GN_ACT, act);
+  if (rc) return rc;
+  if (!y || !dy || !g0 || !stats || !gamma || !beta || !chan_sums) return MC_EINVAL;
+  if (a.cpg != 1 && a.cpg != 2 && a.cpg != 4 && a.cpg != 8) return MC_EUNSUPPORTED;     // a group must lie inside one channel block
+  if ((rc = check_gsrc(g0)) || (rc = check_gsrc(g1))) return rc;
+  dim3 g(a.C8, n);
+  hipStream_t s = (hipStream_t)stream;
+  const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
+  const int CP = a.C8 * 8;
+#define SM(T, GK) hipLaunchKernelGGL((k_gn_bwd_small<T, GK>), g, dim3(1024), 0, s, a, (const T*)y, s0, s1, (T*)dy, chan_sums, CP)
+  if (dtype == MC_F32) SM(float, 0);
+  else if (dtype == MC_BF16) {
+    switch (gkind_of(s0, s1)) { case 1: SM(bf16_t, 1); break; case 2: SM(bf16_t, 2); break; case 3: SM(bf16_t, 3); break; default: SM(bf16_t, 0); }
+  } else return MC_EUNSUPPORTED;
+#undef SM
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_param_grads_batched(const float* const* chan_sums, const int32_t* n, const int32_t* c, float* const* dgamma,
+                              float* const* dbeta, int32_t jobs, void* stream) {
+  if (!chan_sums || !n || !c || !dgamma || !dbeta || jobs <= 0) return MC_EINVAL;
+  for (int base = 0; base < jobs; base += GP_MAX) {
+    GpTable t;
+    t.n = jobs - base < GP_MAX ? jobs - base : GP_MAX;
+    int first = 0;
+    for (int k = 0; k < t.n; ++k) {
+      const int i = base + k;
+      if (!chan_sums[i] || n[i] <= 0 || c[i] <= 0) return MC_EINVAL;
+      t.j[k].pc = chan_sums[i]; t.j[k].dgamma = dgamma[i]; t.j[k].dbeta = dbeta[i];
+      t.j[k].N = n[i]; t.j[k].C = c[i]; t.j[k].CP = ((c[i] + 7) / 8) * 8; t.j[k].first = first;
+      first += ((c[i] + 63) / 64) * 64;
+    }
+    hipLaunchKernelGGL(k_gn_param_grads, dim3(first / 64), dim3(64), 0, (hipStream_t)stream, t);
+  }
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

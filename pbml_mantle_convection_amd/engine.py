@@ -386,6 +386,10 @@ class Engine:
         # momentum residual takes second differences x 126^2 of the output; with 8-bit storage at the full-resolution level
         # its value is rounding noise (2.0 x the exact value at 506^2, tests/study_bf16_momentum.py).
         self.split0 = precision == "mixed"
+        # GroupNorm + activation of layers with at most this many pixels run as ONE launch per direction (statistics + apply
+        # forward; reduce + finalize + apply backward).  MI355X, CFG-3: 64 x 64 and 32 x 32 layers 21 -> 11 us forward and
+        # 38 -> 24 us backward; 128 x 128 layers break even (25 -> 24, 49 -> 53 us: 128 blocks do not fill the chip)
+        self.gn_small_pix = int(os.environ.get("MANTLE_GN_SMALL_PIX", str(64 * 64 + 4)))
 
     # -------------------------------------------------------------- planning
     def freeze(self):
@@ -545,6 +549,9 @@ class Engine:
                 e["gblocks"] = blocks
                 e["gpart"] = torch.empty((N, blocks, coutp, 2), **f32)
                 e["m12"] = torch.empty((N, node.groups, 2), **f32)
+                # small layers: reduce + finalize + apply of the GroupNorm backward in one launch (mc_gn_act_bwd_small)
+                if ho * wo <= self.gn_small_pix and (node.c_out // node.groups) in (1, 2, 4, 8):
+                    e["pc"] = torch.empty((N, coutp, 2), **f32)
             if node.pool > 1:
                 p = T[node.pooled]
                 p.H, p.W = ho // node.pool, wo // node.pool
@@ -791,6 +798,14 @@ class Engine:
                     L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(yout), None,
                            L.ptr(e["part"]) if need_part else None, None, st)
                 self._probe_end(d, "fwd " + node.name)
+            small = (node.post == L.POST_GN_ACT and "pc" in e and not o.fused and "Yf" not in e and node.pool in (1, 2)
+                     and not node.learned and self.fuse == 0)
+            if small:
+                # statistics + activation (+ pooling) of a small layer in one launch
+                pooled = T[node.pooled].buf if node.pool > 1 else None
+                L.call("mc_gn_act_fwd_small", L.ptr(e["Y"]), L.ptr(e["part"]), e["tiles"], N, node.c_out, o.H, o.W, node.groups, 1e-5,
+                       L.ptr(gamma), L.ptr(beta), act, node.pool, self.mc_dtype, L.ptr(e["stats"]), L.ptr(o.buf), L.ptr(pooled), st)
+                continue
             if node.post == L.POST_GN_ACT:
                 # (mean, rstd) per (sample, group) + the (scale, shift, mean, rstd) table consumers normalise on load with
                 L.call("mc_gn_finalize_coef", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
@@ -862,6 +877,7 @@ class Engine:
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
         wg_done = [None, None]
+        gp_jobs = []                                         # GroupNorm parameter gradients of the one-launch layers
         k = 0
         evi = 0
         fo = T[self.plan[-1]["node"].out]
@@ -948,17 +964,22 @@ class Engine:
                 g1 = C.byref(gs[1]) if len(gs) > 1 else None
                 gamma = self._param(params, node.gn_name + "weight") if node.gn_name else None
                 beta = self._param(params, node.gn_name + "bias") if node.gn_name else None
-                if node.post == L.POST_GN_ACT:
-                    L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
-                           L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
-                           L.ptr(e["gpart"]), st)
-                if node.post == L.POST_GN_ACT:
-                    L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
-                           o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
-                           L.ptr(grads[node.gn_name + "bias"]), st)
-                L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
-                       L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
-                       self.mc_dtype, g0, g1, L.ptr(dY), st)
+                if node.post == L.POST_GN_ACT and "pc" in e:
+                    L.call("mc_gn_act_bwd_small", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e["stats"]),
+                           L.ptr(gamma), L.ptr(beta), act, self.mc_dtype, g0, g1, L.ptr(dY), L.ptr(e["pc"]), st)
+                    gp_jobs.append((L.ptr(e["pc"]), node.c_out, L.ptr(grads[node.gn_name + "weight"]),
+                                    L.ptr(grads[node.gn_name + "bias"])))
+                else:
+                    if node.post == L.POST_GN_ACT:
+                        L.call("mc_gn_act_bwd_reduce", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                               L.ptr(e["stats"]), L.ptr(gamma), L.ptr(beta), node.post, act, self.mc_dtype, g0, g1,
+                               L.ptr(e["gpart"]), st)
+                        L.call("mc_gn_act_bwd_finalize", L.ptr(e["gpart"]), N, e["gblocks"], node.c_out, node.groups,
+                               o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
+                               L.ptr(grads[node.gn_name + "bias"]), st)
+                    L.call("mc_gn_act_bwd_apply", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups,
+                           L.ptr(e.get("stats")), L.ptr(e.get("m12")), L.ptr(gamma), L.ptr(beta), node.post, act,
+                           self.mc_dtype, g0, g1, L.ptr(dY), st)
             if node.learned:
                 self._learned_backward(e, srcs[0], dY, params, grads, st)
                 k += 1
@@ -1013,6 +1034,11 @@ class Engine:
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(self.side)
+        if gp_jobs:
+            n = len(gp_jobs)
+            L.call("mc_gn_param_grads_batched", (C.c_void_p * n)(*[j[0] for j in gp_jobs]), (C.c_int32 * n)(*([N] * n)),
+                   (C.c_int32 * n)(*[j[1] for j in gp_jobs]), (C.c_void_p * n)(*[j[2] for j in gp_jobs]),
+                   (C.c_void_p * n)(*[j[3] for j in gp_jobs]), n, st)
         # one launch combines every layer's partial slabs, folds mirrored filters and accumulates into the gradients
         todo = [e for e in self.convs if not e.get("_wfin_done")]
         n = len(todo)
