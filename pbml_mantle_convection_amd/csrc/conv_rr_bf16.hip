@@ -246,11 +246,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
               else gp = (f32x2){act_bwd(z.x, fz.eact), act_bwd(z.y, fz.eact)};
               const f32x2 dA = (f32x2){da[it][2 * h], da[it][2 * h + 1]};
               const f32x2 dz = dA * gp;
-#ifdef MC_RR_DBG_PRINT
-              if (blockIdx.x == 0 && tl == 70 && it == 1 && cb == 0 && h == 0)
-                printf("dbg n %d tile %d ecv %f %f %f %f c0 %f %f %f %f c1 %f %f yy %f %f z %f %f gp %f %f dA %f %f fin %d\n", n, tile, ecv[0], ecv[1], ecv[2], ecv[3],
-                       c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], yy.x, yy.y, z.x, z.y, gp.x, gp.y, dA.x, dA.y, (int)fin[it]);
-#endif
               const f32x2 yh = (yy - (f32x2){c0[2], c1[2]}) * (f32x2){c0[3], c1[3]};
               if (fin[it]) {
                 s[cb][4 * h] += dz.x; s[cb][4 * h + 1] += dz.x * yh.x;
