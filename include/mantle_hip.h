@@ -64,8 +64,10 @@ typedef struct {
   int32_t dtype;      /* MC_F32 | MC_BF16 : element type of x0, x1, y                */
   int32_t sym_h;      /* number of x-mirrored filters (SymmetricConv2d symmetry['h']), 0 = plain Conv2d */
   int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
-  int32_t out_f32;    /* dtype == MC_BF16 only: write y0 as f32 CB8 (the network's last conv: u,v,p,T are not
-                         quantised to bf16); requires c_out <= 16 and no split */
+  int32_t out_f32;    /* dtype == MC_BF16 only: 1 = write y0 as f32 CB8 (the network's last conv: u,v,p,T are not
+                         quantised to bf16); 2 = write the output as a split bf16 pair y0 = bf16(y), y1 = bf16(y - y0)
+                         (same bytes as f32; row-reuse kernel family only, else MC_EUNSUPPORTED); both require
+                         c_out <= 16 and no c_out_split */
   int32_t w_rep_ci;   /* forward filter bank only, 0 = off.  Split-precision sources ("mixed" mode): the launch sees     */
   int32_t w_rep_cs;   /* c_in0 + c_in1 channels but the filter tensor has w_rep_ci; the LAST w_rep_cs channels of the    */
                       /* launch (the lo tensor) repeat the filter's last w_rep_cs channels, launch channels in           */
@@ -232,6 +234,11 @@ int mc_gn_act_fwd_small(const void* y, const float* stat_partials, int32_t tiles
 int mc_gn_act_split_fwd(const float* y_f32, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                         const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
                         void* y_bf16, void* a_hi, void* a_lo, void* stream);
+/* The same from a conv output stored as a split bf16 pair (mc_conv_desc.out_f32 = 2): y = y_hi + y_lo; y_hi doubles as the
+ * bf16 y of the backward pass, so only a_hi / a_lo are written (4 instead of 5 tensor passes). */
+int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                         const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
+                         void* a_hi, void* a_lo, void* stream);
 /* Backward of act(GN(y)) given the gradient sources of a.  Phase 1 reduces
  * (sum dz, sum dz*yhat) per (n,c) into partials [n][blocks][c8*8][2]; phase 2 (finalize)
  * turns them into per-(n,g) means and accumulates dgamma/dbeta (in sample order: deterministic); phase 3 writes dy. */

@@ -257,6 +257,7 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!x0 || !packed_w || !y0 || (g.Cin1 > 0 && !x1) || (g.split8 > 0 && !y1)) return MC_EINVAL;
+  if (g.out_f32 == 2 && (!y1 || !rr_desc(d) || epi)) return !y1 ? MC_EINVAL : MC_EUNSUPPORTED;   // split bf16 pair: row-reuse kernel only
   ConvFuse fz = conv_fuse_none();
   int fuse = fill_prologue(pro, fz, rc);
   if (rc) return rc;

@@ -89,6 +89,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.rep_ci = d->w_rep_ci; g.rep_cs = d->w_rep_cs;
   if (g.rep_cs < 0 || g.rep_ci < 0 || (g.rep_cs > 0 && (g.rep_cs > g.rep_ci || g.rep_ci + g.rep_cs > g.Cin || g.sym_h < 0)))
     return MC_EINVAL;
+  if (g.out_f32 < 0 || g.out_f32 > 2) return MC_EINVAL;
   if (g.out_f32 && (d->c_out > 16 || d->c_out_split != 0)) return MC_EUNSUPPORTED;
   // number of partial slabs of the filter-gradient reduction: enough workgroups to fill the chip
   // (~1024 with the other grid dimensions), bounded by 64 MiB of partials and by the work available

@@ -404,6 +404,31 @@ __global__ void k_gn_act_split(GnArgs a, const float* __restrict__ y, bf16_t* __
   }
 }
 
+__global__ void k_gn_act_split2(GnArgs a, const bf16_t* __restrict__ yh, const bf16_t* __restrict__ yl, bf16_t* __restrict__ hi,
+                                bf16_t* __restrict__ lo) {
+  const int n = (int)blockIdx.z, cb = blockIdx.y;
+  float sc[8], sh[8];
+  gn_coef(a, n, cb, sc, sh);
+  const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
+  const size_t base = ((size_t)n * a.C8 + cb) * a.H * a.W * 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.H * a.W; i += gridDim.x * blockDim.x) {
+    float v[8], vl[8], o[8], h[8], l[8];
+    V8<bf16_t>::ld(yh + base + (size_t)i * 8, v);
+    V8<bf16_t>::ld(yl + base + (size_t)i * 8, vl);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += vl[j];
+    act_fwd8<false>(v, sc, sh, act, o);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const uint32_t p = pk_bf16(o[j], o[j + 1]);
+      h[j] = __uint_as_float(p << 16); h[j + 1] = __uint_as_float(p & 0xffff0000u);
+      l[j] = o[j] - h[j]; l[j + 1] = o[j + 1] - h[j + 1];
+    }
+    V8<bf16_t>::st(hi + base + (size_t)i * 8, h);
+    V8<bf16_t>::st(lo + base + (size_t)i * 8, l);
+  }
+}
+
 template <typename T>
 __global__ void k_avgpool(const T* __restrict__ x, int C8, int H, int W, int f, T* __restrict__ out) {
   const int Hp = H / f, Wp = W / f;
@@ -1524,6 +1549,20 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   else if (dtype == MC_BF16) { if (pool == 1) GN_LAUNCH(bf16_t, 1); else if (pool == 2) GN_LAUNCH(bf16_t, 2); else GN_LAUNCH(bf16_t, 4); }
   else return MC_EUNSUPPORTED;
 #undef GN_LAUNCH
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                         const float* stats, const float* gamma, const float* beta, int32_t post, int32_t act, void* a_hi,
+                         void* a_lo, void* stream) {
+  GnArgs a;
+  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
+  if (rc) return rc;
+  if (!y_hi || !y_lo || !a_hi || !a_lo) return MC_EINVAL;
+  dim3 g(max(1, min(cdiv(h * w, 256 * 4), 4096)), a.C8, n);
+  hipLaunchKernelGGL(k_gn_act_split2, g, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)y_hi, (const bf16_t*)y_lo,
+                     (bf16_t*)a_hi, (bf16_t*)a_lo);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -487,8 +487,16 @@ class Engine:
             lo_of = [s.lo for s in srcs]
             hp_in = (lo_of[-1] is not None and all(x is None for x in lo_of[:-1])
                      and (len(srcs) == 1 or srcs[0].C % 8 == 0))
+            # output of a split layer: a bf16 (hi, lo) pair straight from the row-reuse kernel's epilogue (hi is the y the backward
+            # pass reads: the split-activation pass then moves 4 instead of 5 tensors), f32 from any other kernel family
+            omode = int(final_f32 or split_out)
+            if split_out and not final_f32 and os.environ.get("MANTLE_YPAIR", "1") != "0":
+                d0 = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad, mode,
+                                self.mc_dtype, node.sym_h, 0, 0)
+                if L.load().mc_conv_kernel_name(C.byref(d0)).decode().startswith("k_conv_rr"):
+                    omode = 2
             d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
-                           mode, self.mc_dtype, node.sym_h, 0, int(final_f32 or split_out))
+                           mode, self.mc_dtype, node.sym_h, 0, omode)
             o = T[node.out]
             o.H, o.W = ho, wo
             tiles = L.call("mc_conv_tiles", C.byref(d))
@@ -508,7 +516,11 @@ class Engine:
                      bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
                      need_dgrad=need_dgrad)
             if split_out:
-                e["Yf"] = torch.empty((N, (node.c_out + 7) // 8, ho, wo, 8), dtype=torch.float32, device=device)
+                e["split"] = True
+                if omode == 2:
+                    e["Ylo"] = cb8(node.c_out, ho, wo)
+                else:
+                    e["Yf"] = torch.empty((N, (node.c_out + 7) // 8, ho, wo, 8), dtype=torch.float32, device=device)
                 e["lo"] = cb8(node.c_out, ho, wo)
                 o.lo = e["lo"]
             if hp_in:
@@ -517,13 +529,13 @@ class Engine:
                 c0 = ((cs + 7) // 8) * 8 if len(srcs) == 1 else srcs[0].C + cs        # channels of source 0 of the launch
                 rep = (cin_tot, cs)          # mc_conv_desc.w_rep_ci / w_rep_cs: the bank packer repeats the filters of the split source
                 e["fdesc"] = L.ConvDesc(N, h, w, c0, cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h, 0,
-                                        int(final_f32 or split_out), *rep)
+                                        omode, *rep)
                 if len(srcs) == 2:
                     # [plain ++ hi] ++ lo: the row-reuse kernel takes source 1 in two tensors (x1 = hi, x1b = lo; bank channel
                     # order plain, hi, lo); any other kernel family gets [plain ++ hi] materialised as one tensor
                     # (A/B on MI355X: -0.2 ms per step against the materialised concat; MANTLE_X1B=0 selects the latter)
                     fd3 = L.ConvDesc(N, h, w, srcs[0].C, 2 * cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h,
-                                     0, int(final_f32 or split_out), *rep)
+                                     0, omode, *rep)
                     if (os.environ.get("MANTLE_X1B", "1") != "0"
                             and L.load().mc_conv_kernel_name(C.byref(fd3)).decode().startswith("k_conv_rr")):
                         e["fdesc"], e["x1b"] = fd3, True
@@ -566,7 +578,7 @@ class Engine:
                 pe = self.prod.get(node.srcs[0])
                 if ((self.fuse & 2) and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
                         and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1
-                        and h * w <= self.fuse_maxpix and not hp_in and "Yf" not in pe):
+                        and h * w <= self.fuse_maxpix and not hp_in and not pe.get("split")):
                     dtiles = L.call("mc_conv_tiles", C.byref(dd))
                     fblocks = L.call("mc_fold_blocks", h, w, node.pad, mode)
                     e["epi"] = pe
@@ -779,6 +791,7 @@ class Engine:
             else:
                 self._probe_begin()
                 yout = e["Yf"] if "Yf" in e else e["Y"]
+                ylo = L.ptr(e["Ylo"]) if "Ylo" in e else None
                 if "fdesc" in e:       # split-precision input: (hi, lo) of the last source
                     x0 = srcs[0].buf
                     if "cat0" in e:
@@ -789,16 +802,16 @@ class Engine:
                     if e.get("x1b"):
                         pro = L.ConvPrologue(None, None, 0, 0, L.ptr(srcs[1].lo), srcs[1].C)
                         L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf), C.byref(pro),
-                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), None, L.ptr(e["part"]) if need_part else None, None, st)
+                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), ylo, L.ptr(e["part"]) if need_part else None, None, st)
                     else:
                         L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(x0), L.ptr(srcs[-1].lo), None,
-                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), None, L.ptr(e["part"]) if need_part else None, None, st)
+                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), ylo, L.ptr(e["part"]) if need_part else None, None, st)
                 else:
                     x0, x1, pro = self._sources(srcs)
-                    L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(yout), None,
+                    L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(yout), ylo,
                            L.ptr(e["part"]) if need_part else None, None, st)
                 self._probe_end(d, "fwd " + node.name)
-            small = (node.post == L.POST_GN_ACT and "pc" in e and not o.fused and "Yf" not in e and node.pool in (1, 2)
+            small = (node.post == L.POST_GN_ACT and "pc" in e and not o.fused and not e.get("split") and node.pool in (1, 2)
                      and not node.learned and self.fuse == 0)
             if small:
                 # statistics + activation (+ pooling) of a small layer in one launch
@@ -810,9 +823,13 @@ class Engine:
                 # (mean, rstd) per (sample, group) + the (scale, shift, mean, rstd) table consumers normalise on load with
                 L.call("mc_gn_finalize_coef", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
                        L.ptr(gamma), L.ptr(beta), L.ptr(e["stats"]), L.ptr(e.get("coef")), st)
-            if "Yf" in e:
-                L.call("mc_gn_act_split_fwd", L.ptr(e["Yf"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
-                       L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(e["Y"]), L.ptr(o.buf), L.ptr(e["lo"]), st)
+            if e.get("split"):
+                if "Ylo" in e:
+                    L.call("mc_gn_act_split2_fwd", L.ptr(e["Y"]), L.ptr(e["Ylo"]), N, node.c_out, o.H, o.W, node.groups,
+                           L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(o.buf), L.ptr(e["lo"]), st)
+                else:
+                    L.call("mc_gn_act_split_fwd", L.ptr(e["Yf"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
+                           L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(e["Y"]), L.ptr(o.buf), L.ptr(e["lo"]), st)
                 if node.pool > 1:
                     # (AvgPool2d inside the split pass -- one thread per 2 x 2 block -- measured 0.17 ms SLOWER than this
                     # separate pass: the block-wise access pattern halves the coalescing of the 1.3 GB the split pass moves)

@@ -368,3 +368,57 @@ def test_mixed_precision_mode_on_every_graph(kind):
         assert e_mx <= 1.25 * e_bf + 1e-3, (kind, what, e_mx, e_bf)
     if kind.startswith("unet"):
         assert rel_l2(res["mixed"][0], res["fp32"][0]) < rel_l2(res["bf16"][0], res["fp32"][0])
+
+
+def test_conv_output_as_split_bf16_pair():
+    """mc_conv_desc.out_f32 = 2 (row-reuse kernel): y0 + y1 reproduces the f32 output of the same launch to ~2^-17, y0 is the
+    bf16 rounding of it, the GroupNorm partial sums are identical; mc_gn_act_split2_fwd on the pair == mc_gn_act_split_fwd on
+    the f32 tensor; any other kernel family refuses the mode."""
+    from pbml_mantle_convection_amd import _lib as L
+    lib = L.load()
+    N, H, W, CI, CO, K = 2, 37, 70, 16, 16, 5
+    g = torch.Generator().manual_seed(21)
+    x = _cb8(torch.randn((N, CI, H, W), generator=g), torch.bfloat16)
+    w = (torch.randn((CO, CI, K, K), generator=g) * 0.05).to(DEV)
+    bias = torch.randn(CO, generator=g).to(DEV)
+    st = L.stream()
+    outs = {}
+    for mode in (1, 2):
+        d = L.ConvDesc(N, H, W, CI, 0, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, mode)
+        assert lib.mc_conv_kernel_name(C.byref(d)).decode().startswith("k_conv_rr")
+        tiles = L.call("mc_conv_tiles", C.byref(d))
+        bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=DEV)
+        L.call("mc_pack_weights", C.byref(d), L.ptr(w), 0, L.ptr(bank), st)
+        part = torch.zeros((N, tiles, CO, 2), dtype=torch.float32, device=DEV)
+        if mode == 1:
+            y = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.float32, device=DEV)
+            L.call("mc_conv2d_fused", C.byref(d), L.ptr(x), None, None, L.ptr(bank), L.ptr(bias), L.ptr(y), None, L.ptr(part), None, st)
+            outs[mode] = (y, part)
+        else:
+            yh = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.bfloat16, device=DEV)
+            yl = torch.zeros_like(yh)
+            L.call("mc_conv2d_fused", C.byref(d), L.ptr(x), None, None, L.ptr(bank), L.ptr(bias), L.ptr(yh), L.ptr(yl), L.ptr(part), None, st)
+            outs[mode] = (yh, yl, part)
+            rc = lib.mc_conv2d_fused(C.byref(d), L.ptr(x), None, None, L.ptr(bank), L.ptr(bias), L.ptr(yh), None, L.ptr(part), None, st)
+            assert rc == -1                                   # the pair needs both tensors
+    torch.cuda.synchronize()
+    yf, p1 = outs[1]
+    yh, yl, p2 = outs[2]
+    assert torch.equal(p1, p2)
+    assert torch.equal(yh, yf.to(torch.bfloat16))
+    err = (yh.float() + yl.float() - yf).abs().max()
+    assert float(err) <= 2.0 ** -16 * float(yf.abs().max())
+    # split activation from the pair == from the f32 tensor (same f32 value up to the pair's 2^-17)
+    a1 = [torch.zeros_like(yh) for _ in range(3)]
+    a2 = [torch.zeros_like(yh) for _ in range(2)]
+    L.call("mc_gn_act_split_fwd", L.ptr(yf), N, CO, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(a1[0]), L.ptr(a1[1]),
+           L.ptr(a1[2]), st)
+    L.call("mc_gn_act_split2_fwd", L.ptr(yh), L.ptr(yl), N, CO, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(a2[0]),
+           L.ptr(a2[1]), st)
+    torch.cuda.synchronize()
+    s1 = a1[1].float() + a1[2].float()
+    s2 = a2[0].float() + a2[1].float()
+    assert float((s1 - s2).abs().max()) <= 3e-5 * max(1.0, float(s1.abs().max()))
+    # more than 16 output channels: the mode is refused like the f32 output is
+    dsm = L.ConvDesc(N, H, W, CI, 0, 32, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 2)
+    assert L.call("mc_conv_tiles", C.byref(dsm)) <= 0
