@@ -239,6 +239,10 @@ int mc_gn_act_split_fwd(const float* y_f32, int32_t n, int32_t c, int32_t h, int
 int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                          const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
                          void* a_hi, void* a_lo, void* stream);
+/* ... and AvgPool2d(2)(a), from the f32 values, into pooled [n][c8][h/2][w/2][8] bf16 in the same pass (w even; NULL: none). */
+int mc_gn_act_split2_pool_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                              const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
+                              void* a_hi, void* a_lo, void* pooled, void* stream);
 /* Backward of act(GN(y)) given the gradient sources of a.  Phase 1 reduces
  * (sum dz, sum dz*yhat) per (n,c) into partials [n][blocks][c8*8][2]; phase 2 (finalize)
  * turns them into per-(n,g) means and accumulates dgamma/dbeta (in sample order: deterministic); phase 3 writes dy. */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _vp]),
+    "mc_gn_act_split2_pool_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_gn_act_split2_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "mc_gn_act_split_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_gn_bwd_blocks": (_i32, [_i32, _i32]),

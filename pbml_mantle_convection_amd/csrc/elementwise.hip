@@ -404,15 +404,18 @@ __global__ void k_gn_act_split(GnArgs a, const float* __restrict__ y, bf16_t* __
   }
 }
 
+// POOL2: additionally AvgPool2d(2)(a) from the f32 values.  A thread then handles the pixels (2r, x) and (2r + 1, x), so that
+// rows stay contiguous across lanes, and the horizontal neighbour comes from the adjacent lane (needs an even width).
+template <bool POOL2>
 __global__ void k_gn_act_split2(GnArgs a, const bf16_t* __restrict__ yh, const bf16_t* __restrict__ yl, bf16_t* __restrict__ hi,
-                                bf16_t* __restrict__ lo) {
+                                bf16_t* __restrict__ lo, bf16_t* __restrict__ pooled) {
   const int n = (int)blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8];
   gn_coef(a, n, cb, sc, sh);
   const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
   const size_t base = ((size_t)n * a.C8 + cb) * a.H * a.W * 8;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.H * a.W; i += gridDim.x * blockDim.x) {
-    float v[8], vl[8], o[8], h[8], l[8];
+  auto one = [&](int i, float (&o)[8]) {
+    float v[8], vl[8], h[8], l[8];
     V8<bf16_t>::ld(yh + base + (size_t)i * 8, v);
     V8<bf16_t>::ld(yl + base + (size_t)i * 8, vl);
 #pragma unroll
@@ -426,6 +429,32 @@ __global__ void k_gn_act_split2(GnArgs a, const bf16_t* __restrict__ yh, const b
     }
     V8<bf16_t>::st(hi + base + (size_t)i * 8, h);
     V8<bf16_t>::st(lo + base + (size_t)i * 8, l);
+  };
+  if (!POOL2) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.H * a.W; i += gridDim.x * blockDim.x) {
+      float o[8];
+      one(i, o);
+    }
+  } else {
+    const int Hh = (a.H + 1) / 2, Hp = a.H / 2, Wp = a.W / 2;
+    const int total = Hh * a.W, span = gridDim.x * blockDim.x;           // (span and W are even: lanes 2k, 2k + 1 share a row)
+    for (int i0 = blockIdx.x * blockDim.x; i0 < total; i0 += span) {
+      const int i = i0 + threadIdx.x;
+      const bool live = i < total;
+      const int r = live ? i / a.W : 0, x = live ? i - r * a.W : 0;
+      float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (live) {
+        float o0[8], o1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        one(2 * r * a.W + x, o0);
+        if (2 * r + 1 < a.H) one((2 * r + 1) * a.W + x, o1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] = o0[j] + o1[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s8[j] = 0.25f * (s8[j] + __shfl_xor(s8[j], 1, 64));
+      if (live && (x & 1) == 0 && r < Hp && (x >> 1) < Wp)
+        V8<bf16_t>::st(pooled + (((size_t)n * a.C8 + cb) * Hp * Wp + (size_t)r * Wp + (x >> 1)) * 8, s8);
+    }
   }
 }
 
@@ -1553,18 +1582,32 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   return MC_OK;
 }
 
-int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                         const float* stats, const float* gamma, const float* beta, int32_t post, int32_t act, void* a_hi,
-                         void* a_lo, void* stream) {
+int mc_gn_act_split2_pool_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                              const float* stats, const float* gamma, const float* beta, int32_t post, int32_t act, void* a_hi,
+                              void* a_lo, void* pooled, void* stream) {
   GnArgs a;
   int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
   if (rc) return rc;
   if (!y_hi || !y_lo || !a_hi || !a_lo) return MC_EINVAL;
-  dim3 g(max(1, min(cdiv(h * w, 256 * 4), 4096)), a.C8, n);
-  hipLaunchKernelGGL(k_gn_act_split2, g, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)y_hi, (const bf16_t*)y_lo,
-                     (bf16_t*)a_hi, (bf16_t*)a_lo);
+  if (pooled && ((w & 1) || h < 2)) return MC_EUNSUPPORTED;          // the pooled form pairs adjacent lanes: even width
+  hipStream_t s = (hipStream_t)stream;
+  if (pooled) {
+    dim3 g(max(1, min(cdiv(cdiv(h, 2) * w, 256 * 2), 4096)), a.C8, n);
+    hipLaunchKernelGGL(k_gn_act_split2<true>, g, dim3(256), 0, s, a, (const bf16_t*)y_hi, (const bf16_t*)y_lo, (bf16_t*)a_hi,
+                       (bf16_t*)a_lo, (bf16_t*)pooled);
+  } else {
+    dim3 g(max(1, min(cdiv(h * w, 256 * 4), 4096)), a.C8, n);
+    hipLaunchKernelGGL(k_gn_act_split2<false>, g, dim3(256), 0, s, a, (const bf16_t*)y_hi, (const bf16_t*)y_lo, (bf16_t*)a_hi,
+                       (bf16_t*)a_lo, (bf16_t*)nullptr);
+  }
   MC_CHECK_LAUNCH();
   return MC_OK;
+}
+
+int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
+                         const float* stats, const float* gamma, const float* beta, int32_t post, int32_t act, void* a_hi,
+                         void* a_lo, void* stream) {
+  return mc_gn_act_split2_pool_fwd(y_hi, y_lo, n, c, h, w, groups, stats, gamma, beta, post, act, a_hi, a_lo, nullptr, stream);
 }
 
 int mc_gn_act_split_fwd(const float* y_f32, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,

@@ -824,15 +824,19 @@ class Engine:
                 L.call("mc_gn_finalize_coef", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
                        L.ptr(gamma), L.ptr(beta), L.ptr(e["stats"]), L.ptr(e.get("coef")), st)
             if e.get("split"):
+                pool_here = None
                 if "Ylo" in e:
-                    L.call("mc_gn_act_split2_fwd", L.ptr(e["Y"]), L.ptr(e["Ylo"]), N, node.c_out, o.H, o.W, node.groups,
-                           L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(o.buf), L.ptr(e["lo"]), st)
+                    if node.pool == 2 and o.W % 2 == 0 and os.environ.get("MANTLE_SPLIT_POOL", "1") != "0":
+                        pool_here = T[node.pooled].buf           # AvgPool2d(2) rides in the same pass
+                    L.call("mc_gn_act_split2_pool_fwd", L.ptr(e["Y"]), L.ptr(e["Ylo"]), N, node.c_out, o.H, o.W, node.groups,
+                           L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(o.buf), L.ptr(e["lo"]),
+                           L.ptr(pool_here), st)
                 else:
                     L.call("mc_gn_act_split_fwd", L.ptr(e["Yf"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
                            L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(e["Y"]), L.ptr(o.buf), L.ptr(e["lo"]), st)
-                if node.pool > 1:
-                    # (AvgPool2d inside the split pass -- one thread per 2 x 2 block -- measured 0.17 ms SLOWER than this
-                    # separate pass: the block-wise access pattern halves the coalescing of the 1.3 GB the split pass moves)
+                if node.pool > 1 and pool_here is None:
+                    # (a first form of the pooled split pass -- one thread per 2 x 2 block -- measured 0.17 ms SLOWER than this
+                    # separate pass: the block-wise access pattern halves the coalescing; the row-pair form above keeps it)
                     L.call("mc_avgpool_fwd", L.ptr(o.buf), N, node.c_out, o.H, o.W, node.pool, self.mc_dtype,
                            L.ptr(T[node.pooled].buf), st)
             elif o.fused:

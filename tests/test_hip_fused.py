@@ -419,6 +419,15 @@ def test_conv_output_as_split_bf16_pair():
     s1 = a1[1].float() + a1[2].float()
     s2 = a2[0].float() + a2[1].float()
     assert float((s1 - s2).abs().max()) <= 3e-5 * max(1.0, float(s1.abs().max()))
+    # the pooled form of the pass: same hi / lo, AvgPool2d(2) of the f32 activation
+    a3 = [torch.zeros_like(yh) for _ in range(2)]
+    pl = torch.zeros((N, CO // 8, H // 2, W // 2, 8), dtype=torch.bfloat16, device=DEV)
+    L.call("mc_gn_act_split2_pool_fwd", L.ptr(yh), L.ptr(yl), N, CO, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(a3[0]),
+           L.ptr(a3[1]), L.ptr(pl), st)
+    torch.cuda.synchronize()
+    assert torch.equal(a3[0], a2[0]) and torch.equal(a3[1], a2[1])
+    pref = torch.nn.functional.avg_pool2d(torch.nn.functional.gelu(_from_cb8(yh, CO).double() + _from_cb8(yl, CO).double()), 2)
+    assert float((_from_cb8(pl, CO).double() - pref).abs().max()) <= 1e-2 * float(pref.abs().max())
     # more than 16 output channels: the mode is refused like the f32 output is
     dsm = L.ConvDesc(N, H, W, CI, 0, 32, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 2)
     assert L.call("mc_conv_tiles", C.byref(dsm)) <= 0
