@@ -16,7 +16,7 @@
  *  - Return 0 on success; MC_E* (negative) for argument/shape/unsupported errors;
  *    positive values are hipError_t codes from the launch.  Nothing throws or aborts.
  *  - Activations use the CB8 layout: [N][C8][H][W][8] with C8 = ceil(C/8) channel blocks,
- *    element type f32 (MC_F32) or bf16 (MC_BF16).  Padded channels hold zeros.
+ *    element type f32 (MC_F32), bf16 (MC_BF16) or f16 forward / bf16 gradients (MC_MIX16).  Padded channels hold zeros.
  *    Network inputs/outputs and loss fields are plain NCHW / NHW f32.
  *  - Parameters are read in the REFERENCE's layout (unique mirrored-filter bank
  *    [U][C_in][k][k] f32, bias [C_out] f32; symmetric_layers_torch.py:96-107).
@@ -36,7 +36,13 @@ extern "C" {
 #define MC_EUNSUPPORTED (-2)
 #define MC_EWORKSPACE (-3)
 
-enum { MC_F32 = 0, MC_BF16 = 1 };
+/* MC_MIX16 (the trainer's "mixed" precision): every tensor of the FORWARD pass (packed input, filter banks of the forward
+ * convolutions, raw conv outputs, activations, pooled / upsampled tensors) is IEEE f16, every GRADIENT tensor (dY, dA,
+ * padded-domain input gradients, their filter banks) is bf16; MFMA arithmetic with f32 accumulation either way.  An entry
+ * point that takes `dtype` reads / writes each of its operands in the type of that operand's role: forward-only calls
+ * (mc_pack_nchw, mc_gn_act_fwd, mc_bicubic_fwd ...) move f16, gradient-only calls (mc_fold_padded, mc_bicubic_bwd ...) move
+ * bf16, the GroupNorm-backward and filter-gradient calls read y / x as f16 and gradients as bf16. */
+enum { MC_F32 = 0, MC_BF16 = 1, MC_MIX16 = 2 };
 enum { MC_PAD_ZEROS = 0, MC_PAD_REPLICATE = 1, MC_PAD_REFLECT = 2 };
 enum { MC_ACT_NONE = 0, MC_ACT_GELU = 1, MC_ACT_RELU = 2, MC_ACT_SILU = 3, MC_ACT_TANH = 4,
        MC_ACT_SELU = 5, MC_ACT_ELU = 6 };
@@ -61,7 +67,8 @@ typedef struct {
   int32_t k;          /* square kernel, 3 or 5                                       */
   int32_t pad;        /* per side; output is (h + 2 pad - k + 1) x (w + 2 pad - k + 1) */
   int32_t pad_mode;   /* MC_PAD_*                                                    */
-  int32_t dtype;      /* MC_F32 | MC_BF16 : element type of x0, x1, y                */
+  int32_t dtype;      /* MC_F32 | MC_BF16 | MC_MIX16 : element type of x0, x1, y (MC_MIX16: f16; the input-gradient
+                         convolution of such a layer is described with MC_BF16)       */
   int32_t sym_h;      /* number of x-mirrored filters (SymmetricConv2d symmetry['h']), 0 = plain Conv2d */
   int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
   int32_t out_f32;    /* dtype == MC_BF16 only: 1 = write y0 as f32 CB8 (the network's last conv: u,v,p,T are not
@@ -116,6 +123,7 @@ typedef struct {
   int32_t hs, ws;     /* interior (unpadded) size */
   float* partials;    /* [n][part_stride][c8*8][2] f32; this launch fills slots 0 .. mc_conv_tiles(desc) - 1 of a sample */
   int32_t part_stride;/* slots per sample (>= tiles; the slots behind the tiles are mc_fold_padded_dz's) */
+  int32_t y_f16;      /* 1: y is f16 -- the layer belongs to an MC_MIX16 network (the launch itself is MC_BF16); else 0 */
 } mc_conv_epilogue;
 
 int mc_version(void);

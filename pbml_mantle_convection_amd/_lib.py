@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MANTLE_LIB", os.path.join(_HERE, "libmantle_hip.so"))
 
-MC_F32, MC_BF16 = 0, 1
+MC_F32, MC_BF16, MC_MIX16 = 0, 1, 2
 PAD_MODES = {"zeros": 0, "constant": 0, "replicate": 1, "reflect": 2}
 ACTS = {"none": 0, "gelu": 1, "relu": 2, "silu": 3, "tanh": 4, "selu": 5, "elu": 6}
 POST_NONE, POST_ACT, POST_GN_ACT = 0, 1, 2
@@ -38,7 +38,8 @@ class ConvPrologue(C.Structure):
 class ConvEpilogue(C.Structure):
     """mc_conv_epilogue: dz = dA * act'(z) + GroupNorm-backward partial sums in the input-gradient launch."""
     _fields_ = [("y", C.c_void_p), ("coef", C.c_void_p), ("act", C.c_int32), ("pad", C.c_int32), ("pad_mode", C.c_int32),
-                ("hs", C.c_int32), ("ws", C.c_int32), ("partials", C.c_void_p), ("part_stride", C.c_int32)]
+                ("hs", C.c_int32), ("ws", C.c_int32), ("partials", C.c_void_p), ("part_stride", C.c_int32),
+                ("y_f16", C.c_int32)]
 
 
 class LossDesc(C.Structure):

@@ -27,6 +27,19 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((mc_f32x2){a, b}, mc_bf16x2));
 }
 
+// IEEE half as a storage type of its own (MC_MIX16: every FORWARD tensor is f16 -- 11 significant bits, the momentum
+// residual's second differences need them -- while gradient tensors stay bf16 for their range)
+struct f16_t { uint16_t v; };
+typedef _Float16 mc_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {       // v_cvt_pk_f16_f32 (RNE)
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((mc_f32x2){a, b}, mc_f16x2));
+}
+__device__ __forceinline__ mc_f32x2 unpk_f16(uint32_t w) {
+  return __builtin_convertvector(__builtin_bit_cast(mc_f16x2, w), mc_f32x2);
+}
+// the same value after a round trip through the 16-bit storage type T (f32: unchanged)
+template <typename T> __device__ __forceinline__ float round_storage(float v) { return v; }
+
 // ---- 8-channel vector access in the CB8 layout ------------------------------------------------
 template <typename T> struct V8;
 template <> struct V8<float> {
@@ -57,6 +70,19 @@ template <> struct V8<bf16_t> {
     *reinterpret_cast<uint4*>(p) = a;
   }
 };
+
+template <> struct V8<f16_t> {
+  static __device__ __forceinline__ void ld(const f16_t* p, float (&o)[8]) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    const mc_f32x2 x = unpk_f16(a.x), y = unpk_f16(a.y), z = unpk_f16(a.z), w = unpk_f16(a.w);
+    o[0] = x.x; o[1] = x.y; o[2] = y.x; o[3] = y.y; o[4] = z.x; o[5] = z.y; o[6] = w.x; o[7] = w.y;
+  }
+  static __device__ __forceinline__ void st(f16_t* p, const float (&o)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pk_f16(o[0], o[1]), pk_f16(o[2], o[3]), pk_f16(o[4], o[5]), pk_f16(o[6], o[7]));
+  }
+};
+template <> __device__ __forceinline__ float round_storage<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float round_storage<f16_t>(float v) { return (float)(_Float16)v; }
 
 __device__ __forceinline__ size_t cb8_index(int n, int cb, int y, int x, int C8, int H, int W) {
   return ((((size_t)n * C8 + cb) * H + y) * (size_t)W + x) * 8;
@@ -214,6 +240,9 @@ __device__ __forceinline__ void act_bwd8(const float (&v)[8], const float (&sc)[
 }
 template <typename T> struct FastMath { static constexpr bool value = false; };
 template <> struct FastMath<bf16_t> { static constexpr bool value = true; };
+template <> struct FastMath<f16_t> { static constexpr bool value = true; };
+// MC_BF16 / MC_MIX16: 16-bit storage on the MFMA path
+__host__ __device__ inline bool mc_is16(int dtype) { return dtype == MC_BF16 || dtype == MC_MIX16; }
 
 // ---- GroupNorm + activation applied by the CONSUMER of a raw conv output ("normalise on load") -----------------
 // coef4: [n][CP][4] f32 = (scale, shift, mean, rstd) per (sample, channel), written by mc_gn_finalize_coef with the
@@ -245,6 +274,18 @@ __device__ __forceinline__ uint4 xform_bf16x8(uint4 a, const float (&sc)[8], con
   o.z = pk_bf16(v[4], v[5]);
   o.w = pk_bf16(v[6], v[7]);
   return o;
+}
+
+__device__ __forceinline__ uint4 xform_f16x8(uint4 a, const float (&sc)[8], const float (&sh)[8], int act) {
+  float v[8];
+  V8<f16_t>::ld(reinterpret_cast<const f16_t*>(&a), v);
+  act_fwd8<true>(v, sc, sh, act, v);
+  return make_uint4(pk_f16(v[0], v[1]), pk_f16(v[2], v[3]), pk_f16(v[4], v[5]), pk_f16(v[6], v[7]));
+}
+// f16 CB8 vector -> bf16 CB8 vector (the filter-gradient kernel reads the f16 activations of the forward pass)
+__device__ __forceinline__ uint4 f16x8_to_bf16x8(uint4 a) {
+  const mc_f32x2 x = unpk_f16(a.x), y = unpk_f16(a.y), z = unpk_f16(a.z), w = unpk_f16(a.w);
+  return make_uint4(pk_bf16(x.x, x.y), pk_bf16(y.x, y.y), pk_bf16(z.x, z.y), pk_bf16(w.x, w.y));
 }
 
 // ---- wave / block reductions (wave = 64) --------------------------------------------------------

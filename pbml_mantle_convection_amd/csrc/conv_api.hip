@@ -34,13 +34,13 @@ bool rr_desc(const mc_conv_desc* d) {
 int geom_for(const mc_conv_desc* d, ConvGeom& g) {
   if (!d) return MC_EINVAL;
   int th = 16, tw = 16;
-  if (d->dtype == MC_BF16) {
+  if (mc_is16(d->dtype)) {
     if (rr_desc(d)) { th = RR_R; tw = RR_TW; }
     else {
       int rc = mc_bf16_tile(d, &th, &tw);
       if (rc) return rc;
     }
-  } else if (d->dtype != MC_F32) {
+  } else if (d->dtype != MC_F32) {        // (MC_BF16 and MC_MIX16 share every tile shape and bank size)
     return MC_EUNSUPPORTED;
   }
   return conv_geom(d, th, tw, g);
@@ -57,7 +57,7 @@ __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, 
 // ---- batched packing: the job table travels by value in the kernel arguments (<= PK_MAX jobs per launch)
 struct PkJob {
   int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP, rep_ci, rep_cs;
-  int dgrad, steps, ntiles, bf16, rr, first_block;
+  int dgrad, steps, ntiles, bf16, f16, rr, first_block;
   unsigned total;
   const float* w;
   void* out;
@@ -72,9 +72,13 @@ __global__ void k_pack_batched(PkTable t) {
   const PkJob& job = t.j[ji];
   const int nblk = (ji + 1 < t.n ? t.j[ji + 1].first_block : (int)gridDim.x) - job.first_block;
   for (size_t i = (size_t)(blockIdx.x - job.first_block) * blockDim.x + threadIdx.x; i < job.total; i += (size_t)nblk * blockDim.x) {
-    if (job.rr) reinterpret_cast<bf16_t*>(job.out)[i] = f2bf(rr_pack_value(job, job.w, i, job.dgrad, job.ntiles));
-    else if (job.bf16) reinterpret_cast<bf16_t*>(job.out)[i] = f2bf(pack_value_bf16(job, job.w, i, job.dgrad, job.steps, job.ntiles));
-    else reinterpret_cast<float*>(job.out)[i] = pack_value_f32(job, job.w, i, job.dgrad);
+    if (job.rr || job.bf16) {
+      const float v = job.rr ? rr_pack_value(job, job.w, i, job.dgrad, job.ntiles)
+                             : pack_value_bf16(job, job.w, i, job.dgrad, job.steps, job.ntiles);
+      reinterpret_cast<bf16_t*>(job.out)[i] = job.f16 ? __builtin_bit_cast(bf16_t, (_Float16)v) : f2bf(v);
+    } else {
+      reinterpret_cast<float*>(job.out)[i] = pack_value_f32(job, job.w, i, job.dgrad);
+    }
   }
 }
 
@@ -200,7 +204,7 @@ size_t mc_packed_weight_bytes(const mc_conv_desc* d, int32_t dgrad) {
   ConvGeom g;
   if (geom_for(d, g)) return 0;
   if (bank_is_rr(g, dgrad)) return mc_rr_bank_bytes(g, dgrad);
-  if (g.dtype == MC_BF16) return mc_bf16_bank_bytes(g, dgrad);
+  if (mc_is16(g.dtype)) return mc_bf16_bank_bytes(g, dgrad);
   int cbin = dgrad ? g.CBout : g.CBin, cop = dgrad ? g.CinP : g.CoutP;
   return (size_t)cbin * g.K * g.K * 8 * cop * sizeof(float);
 }
@@ -212,7 +216,7 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
   if (!w_unique || !packed) return MC_EINVAL;
   if (dgrad) g.rep_ci = g.rep_cs = 0;                       // (the filter repeat describes the forward bank only)
   if (bank_is_rr(g, dgrad)) return mc_rr_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
-  if (g.dtype == MC_BF16) return mc_bf16_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
+  if (mc_is16(g.dtype)) return mc_bf16_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   size_t total = mc_packed_weight_bytes(d, dgrad) / sizeof(float);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
@@ -225,7 +229,7 @@ const char* mc_conv_kernel_name(const mc_conv_desc* d) {
   ConvGeom g;
   if (geom_for(d, g)) return "unsupported";
   if (rr_desc(d)) return mc_rr_kernel_name(g, 0);
-  if (g.dtype == MC_BF16) return mc_bf16_kernel_name(g);
+  if (mc_is16(g.dtype)) return mc_bf16_kernel_name(g);
   return g.K == 5 ? "k_conv_direct_f32<5>" : "k_conv_direct_f32<3>";
 }
 
@@ -270,13 +274,15 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
     if (g.Ho != epi->hs + 2 * epi->pad || g.Wo != epi->ws + 2 * epi->pad) return MC_EINVAL;
     fz.ey = epi->y; fz.ecoef = epi->coef; fz.epart = epi->partials; fz.eact = epi->act; fz.epad = epi->pad;
     fz.ezero = epi->pad_mode == MC_PAD_ZEROS || epi->pad == 0; fz.ehs = epi->hs; fz.ews = epi->ws;
+    if (epi->y_f16 && g.dtype != MC_BF16) return MC_EINVAL;   // (an f16 y belongs to the bf16 input-gradient launch of an MC_MIX16 layer)
+    fz.ey16 = epi->y_f16 ? 1 : 0;
     if (epi->part_stride < stat_slots(d, g)) return MC_EINVAL;
     fz.estride = epi->part_stride;
     fuse = 2;
   }
   if (fz.x1b && (!rr_desc(d) || fz.cb1a >= g.CB1 || epi)) return fz.cb1a >= g.CB1 ? MC_EINVAL : MC_EUNSUPPORTED;
   if (rr_desc(d)) return mc_conv2d_rr(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
-  if (g.dtype == MC_BF16) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
+  if (mc_is16(g.dtype)) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   return mc_conv2d_f32(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
 }
 
@@ -301,7 +307,7 @@ int mc_conv2d_wgrad_fused(const mc_conv_desc* d, const void* x0, const void* x1,
   const int fuse = fill_prologue(pro, fz, rc);
   if (rc) return rc;
   if (fz.x1b) return MC_EUNSUPPORTED;
-  if (g.dtype == MC_BF16) return mc_wgrad_bf16(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
+  if (mc_is16(g.dtype)) return mc_wgrad_bf16(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
   return mc_wgrad_f32(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
 }
 
@@ -361,7 +367,8 @@ int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_uni
       if (!w_unique[base + k] || !packed[base + k]) return MC_EINVAL;
       PkJob& j = t.j[k];
       j.K = g.K; j.Cout = g.Cout; j.CBin = g.CBin; j.CB0 = g.CB0; j.Cin0 = g.Cin0; j.Cin1 = g.Cin1; j.Cin = g.Cin; j.U = g.U;
-      j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = g.dtype == MC_BF16;
+      j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = mc_is16(g.dtype);
+      j.f16 = (g.dtype == MC_MIX16 && !j.dgrad) ? 1 : 0;       // forward banks of MC_MIX16 are f16, input-gradient banks bf16
       j.rep_ci = j.dgrad ? 0 : g.rep_ci; j.rep_cs = j.dgrad ? 0 : g.rep_cs;
       j.rr = bank_is_rr(g, j.dgrad);
       size_t total;

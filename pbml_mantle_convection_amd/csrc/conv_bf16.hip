@@ -19,6 +19,7 @@
 #include <type_traits>
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
@@ -47,10 +48,19 @@ __host__ __device__ inline int pick_nt(int n_tiles) { return (n_tiles % 4 == 0) 
 //   with pair j = 4 s + g, tap = j / 2, cb = j % 2.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad, bf16_t* __restrict__ bank,
-                            int chunks, int steps, int ntiles) {
+                            int chunks, int steps, int ntiles, int f16) {
   const size_t total = (size_t)chunks * steps * ntiles * 64 * 8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    bank[i] = f2bf(pack_value_bf16(g, wu, i, dgrad, steps, ntiles));
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = pack_value_bf16(g, wu, i, dgrad, steps, ntiles);
+    bank[i] = f16 ? __builtin_bit_cast(bf16_t, (_Float16)v) : f2bf(v);
+  }
+}
+
+// H16 (MC_MIX16): FUSE 0 / 1 = forward convolution on f16 operands with an f16 output; FUSE 2 = input-gradient convolution
+// (bf16) whose epilogue reads the producer's raw output y as f16 (see conv_rr_bf16.hip)
+template <bool H16> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -73,7 +83,7 @@ __global__ void k_pack_bf16(ConvGeom g, const float* __restrict__ wu, int dgrad,
 #endif
 // FUSE: 0 = plain; 1 = prologue (the sources are raw conv outputs: GroupNorm affine + activation applied while the tile
 // is staged); 2 = input-gradient epilogue (dz = dA * act'(z) and the GroupNorm-backward partial sums instead of dA).
-template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false, int FUSE = 0>
+template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false, int FUSE = 0, bool H16 = false>
 #ifndef MC_CONV_WAVES
 #define MC_CONV_WAVES 2
 #endif
@@ -194,7 +204,8 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 #pragma unroll
         for (int it = 0; it < PER_CB; ++it)
           if (s_lds[it] >= 0) {
-            uint4 v = xform_bf16x8(make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]), psc[cb], psh[cb], pact[cb]);
+            const uint4 raw = make_uint4(rin[cb][it][0], rin[cb][it][1], rin[cb][it][2], rin[cb][it][3]);
+            uint4 v = H16 ? xform_f16x8(raw, psc[cb], psh[cb], pact[cb]) : xform_bf16x8(raw, psc[cb], psh[cb], pact[cb]);
             if (!((okm >> it) & 1u)) v = make_uint4(0, 0, 0, 0);
             in_s[cb * PLANE + s_lds[it]] = v;
           }
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt], xf[i], acc[i][tt], 0, 0, 0);
+        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = mfma16<(H16 && FUSE != 2)>(wf[tt], xf[i], acc[i][tt]);
     };
 #ifndef MC_KPIPE
 #define MC_KPIPE 0
@@ -392,8 +403,8 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
               *reinterpret_cast<float4*>(dst0[tt] + off) = make_float4(v01.x, v01.y, v23.x, v23.y);
             } else {
               uint2 pk;
-              pk.x = (uint32_t)f2bf(v01.x) | ((uint32_t)f2bf(v01.y) << 16);
-              pk.y = (uint32_t)f2bf(v23.x) | ((uint32_t)f2bf(v23.y) << 16);
+              if constexpr (H16) { pk.x = pk_f16(v01.x, v01.y); pk.y = pk_f16(v23.x, v23.y); }
+              else { pk.x = pk_bf16(v01.x, v01.y); pk.y = pk_bf16(v23.x, v23.y); }
               *reinterpret_cast<uint2*>(dst0[tt] + off) = pk;
             }
           }
@@ -436,8 +447,14 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
           const int oy = oy0 + i / MTILES_X, ox = ox0 + (i % MTILES_X) * 16;
           const bool inb = oy < g.Ho && ox < g.Wo;
           const size_t off = (size_t)(i / MTILES_X) * row_bytes + (size_t)(i % MTILES_X) * 16 * 8 * 2;
-          const float yf[4] = {__uint_as_float(yv[i].x << 16), __uint_as_float(yv[i].x & 0xffff0000u),
-                               __uint_as_float(yv[i].y << 16), __uint_as_float(yv[i].y & 0xffff0000u)};
+          float yf[4];
+          if constexpr (H16) {
+            const f32x2 ya = unpk_f16(yv[i].x), yb = unpk_f16(yv[i].y);
+            yf[0] = ya.x; yf[1] = ya.y; yf[2] = yb.x; yf[3] = yb.y;
+          } else {
+            yf[0] = __uint_as_float(yv[i].x << 16); yf[1] = __uint_as_float(yv[i].x & 0xffff0000u);
+            yf[2] = __uint_as_float(yv[i].y << 16); yf[3] = __uint_as_float(yv[i].y & 0xffff0000u);
+          }
           float o[4];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -538,7 +555,8 @@ constexpr int WTH = 16, WTW = 32;      // work-item tile (output pixels)
 // two column blocks; RS 4: 7/6/6/6 taps, the whole tile (no cross-wave sum).  The bias gradient rides in the spare
 // slot of the last tap group.  Column groups are summed through LDS once per workgroup.
 // PRO: x0 / x1 are raw conv outputs; the producer's GroupNorm affine + activation are applied while the tile is staged.
-template <int K, int NTW, int RS, bool PRO = false>
+// XH (MC_MIX16): x0 / x1 are f16 tensors of the forward pass, converted to bf16 while the tile is staged (dy is bf16).
+template <int K, int NTW, int RS, bool PRO = false, bool XH = false>
 __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mfma_bf16(ConvGeom g, const bf16_t* __restrict__ x0,
                                                             const bf16_t* __restrict__ x1, const bf16_t* __restrict__ dy,
                                                             float* __restrict__ part, int tiles_x, int tiles, ConvFuse fz) {
@@ -710,8 +728,10 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
         if (v >= 0) {
           uint4 q = rx[cb][it];
           if (PRO && pact[cb] >= 0) {
-            q = xform_bf16x8(q, psc[cb], psh[cb], pact[cb]);
+            q = XH ? f16x8_to_bf16x8(xform_f16x8(q, psc[cb], psh[cb], pact[cb])) : xform_bf16x8(q, psc[cb], psh[cb], pact[cb]);
             if (!((okm >> it) & 1u)) q = make_uint4(0, 0, 0, 0);
+          } else if (XH) {
+            q = f16x8_to_bf16x8(q);
           }
           xs[cb * XPS + ((v >> 15) & 0x7fff) * XRS + (v & 0x7fff)] = q;
         }
@@ -944,7 +964,8 @@ int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hip
   size_t total = (size_t)chunks * steps * ntiles * 64 * 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_pack_bf16, dim3(blocks), dim3(256), 0, s, g, w, dgrad, (bf16_t*)packed, chunks, steps, ntiles);
+  hipLaunchKernelGGL(k_pack_bf16, dim3(blocks), dim3(256), 0, s, g, w, dgrad, (bf16_t*)packed, chunks, steps, ntiles,
+                     (g.dtype == MC_MIX16 && !dgrad) ? 1 : 0);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -968,10 +989,13 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
   int bx = items < cap ? items : cap;
   dim3 grid(bx, groups, 1);
   if (fuse == 2 && g.out_f32) return MC_EUNSUPPORTED;
-#define LAUNCH_F(K, TH, TW, NT, MT, F32, FU)                                                                           \
-  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT, F32, FU>), grid, dim3(64 * (TH * (TW / 16) / MT)), 0, s, g,  \
+  const bool h16 = fuse == 2 ? fz.ey16 != 0 : g.dtype == MC_MIX16;
+#define LAUNCH_H(K, TH, TW, NT, MT, F32, FU, H)                                                                        \
+  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT, F32, FU, H>), grid, dim3(64 * (TH * (TW / 16) / MT)), 0, s, g, \
                      (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part,  \
                      groups, fz)
+#define LAUNCH_F(K, TH, TW, NT, MT, F32, FU)                                                                           \
+  do { if (h16) LAUNCH_H(K, TH, TW, NT, MT, F32, FU, true); else LAUNCH_H(K, TH, TW, NT, MT, F32, FU, false); } while (0)
 #define LAUNCH(K, TH, TW, NT, MT, F32)                                                                                 \
   do { if (fuse == 0) LAUNCH_F(K, TH, TW, NT, MT, F32, 0); else if (fuse == 1) LAUNCH_F(K, TH, TW, NT, MT, F32, 1);   \
        else LAUNCH_F(K, TH, TW, NT, MT, false, 2); } while (0)
@@ -986,6 +1010,7 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
   }
 #undef LAUNCH
 #undef LAUNCH_F
+#undef LAUNCH_H
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -998,9 +1023,11 @@ int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const vo
   const int ntiles = (g.Cout + 15) / 16;
   const int ntw = pick_nt(ntiles) >= 2 ? 2 : 1;      // two co-tiles per block keep LDS at 55 KB (2-3 blocks per CU)
   dim3 grid(g.wgrad_G, (g.CBin + 1) / 2, (ntiles + ntw - 1) / ntw);
-#define WLAUNCH_P(K, NTW, RS, PRO)                                                                                     \
-  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW, RS, PRO>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, \
+  const bool xh = g.dtype == MC_MIX16;
+#define WLAUNCH_X(K, NTW, RS, PRO, XH)                                                                                 \
+  hipLaunchKernelGGL((k_wgrad_mfma_bf16<K, NTW, RS, PRO, XH>), grid, dim3(256), 0, s, g, (const bf16_t*)x0, (const bf16_t*)x1, \
                      (const bf16_t*)dy, (float*)part, tiles_x, tiles, fz)
+#define WLAUNCH_P(K, NTW, RS, PRO) do { if (xh) WLAUNCH_X(K, NTW, RS, PRO, true); else WLAUNCH_X(K, NTW, RS, PRO, false); } while (0)
 #define WLAUNCH(K, NTW, RS) do { if (fuse) WLAUNCH_P(K, NTW, RS, true); else WLAUNCH_P(K, NTW, RS, false); } while (0)
   // A/B knob: two decimal digits = tap groups for (one co-tile, two co-tiles); 0 = the row-at-a-time kernel.  Measured
   // alone at level 0 (16->16, 32x506x512): 0: 266 us, 1: 171, 2: 203, 4: 155; 64->64 at 63x64: 0: 44 us, 4: 37.  Inside
@@ -1014,6 +1041,7 @@ int mc_wgrad_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const vo
 #undef WPICK
 #undef WLAUNCH
 #undef WLAUNCH_P
+#undef WLAUNCH_X
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

@@ -29,12 +29,13 @@ struct ConvFuse {
   int eact, epad, ezero, ehs, ews;          // ezero: forward padding was zeros (every interior pixel is final)
   int estride;                              // slots per sample of epart
   const void* x1b; int cb1a;                // source 1 held in two tensors: blocks [0, cb1a) from x1, the rest from x1b
+  int ey16;                                 // epilogue: ey is f16 (MC_MIX16 forward tensors), else the launch's element type
 };
 static inline ConvFuse conv_fuse_none() {
   ConvFuse f;
   f.coef0 = f.coef1 = nullptr; f.act0 = f.act1 = MC_ACT_NONE;
   f.ey = nullptr; f.ecoef = nullptr; f.epart = nullptr; f.eact = MC_ACT_NONE; f.epad = 0; f.ezero = 1; f.ehs = f.ews = 0; f.estride = 0;
-  f.x1b = nullptr; f.cb1a = 0;
+  f.x1b = nullptr; f.cb1a = 0; f.ey16 = 0;
   return f;
 }
 
@@ -85,7 +86,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.tiles = g.tiles_x * g.tiles_y;
   g.sym_h = d->sym_h; g.U = d->c_out - d->sym_h / 2;
   g.dtype = d->dtype;
-  g.out_f32 = (d->dtype == MC_BF16) ? d->out_f32 : 0;
+  g.out_f32 = mc_is16(d->dtype) ? d->out_f32 : 0;
   g.rep_ci = d->w_rep_ci; g.rep_cs = d->w_rep_cs;
   if (g.rep_cs < 0 || g.rep_ci < 0 || (g.rep_cs > 0 && (g.rep_cs > g.rep_ci || g.rep_ci + g.rep_cs > g.Cin || g.sym_h < 0)))
     return MC_EINVAL;
@@ -97,7 +98,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   long cap = (64L << 20) / slab;
   if (cap < 32) cap = 32;
   long G, work;
-  if (g.dtype == MC_BF16) {
+  if (mc_is16(g.dtype)) {
     int ntiles = (g.Cout + 15) / 16;
     int ntw = (ntiles % 2 == 0) ? 2 : 1;
     long other = (long)((g.CBin + 1) / 2) * ((ntiles + ntw - 1) / ntw);

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
@@ -47,9 +48,23 @@ __device__ __forceinline__ int rr_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-__global__ void k_pack_rr(ConvGeom g, const float* __restrict__ wu, int dgrad, bf16_t* __restrict__ bank, int ntiles, size_t total) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    bank[i] = f2bf(rr_pack_value(g, wu, i, dgrad, ntiles));
+__global__ void k_pack_rr(ConvGeom g, const float* __restrict__ wu, int dgrad, bf16_t* __restrict__ bank, int ntiles, size_t total, int f16) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = rr_pack_value(g, wu, i, dgrad, ntiles);
+    bank[i] = f16 ? __builtin_bit_cast(bf16_t, (_Float16)v) : f2bf(v);
+  }
+}
+
+// 16-bit element type of a launch.  H16 = false: bf16 everywhere.  H16 = true (MC_MIX16): FUSE 0 / 1 = a forward
+// convolution whose sources, filter bank and (16-bit) output are f16; FUSE 2 = an input-gradient convolution (bf16 operands
+// and output) whose epilogue reads the producer's raw output y as f16.
+template <bool H16> __device__ __forceinline__ f32x4 rr_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool H16> __device__ __forceinline__ uint32_t rr_pk(float a, float b) {
+  if constexpr (H16) return pk_f16(a, b);
+  else return pk_bf16(a, b);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -60,7 +75,7 @@ __global__ void k_pack_rr(ConvGeom g, const float* __restrict__ wu, int dgrad, b
 //   filter fragments of a one-chunk layer are staged through it once, before its first use; several chunks (a rare
 //   shape): the MFMA waves fetch their fragments from global memory per stage.
 // GELU: every fused activation is GELU (inline polynomial); otherwise the generic activation switch is compiled in.
-template <int K, int FUSE, bool OUT_F32, bool GELU>
+template <int K, int FUSE, bool OUT_F32, bool GELU, bool H16 = false>
 __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
                                                          const bf16_t* __restrict__ bank, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y0, bf16_t* __restrict__ y1,
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #pragma unroll
             for (int it = 0; it < YPER; ++it) {
               const unsigned yw = yv[cb][it][h];
-              const f32x2 yy = (f32x2){__uint_as_float(yw << 16), __uint_as_float(yw & 0xffff0000u)};
+              const f32x2 yy = H16 ? unpk_f16(yw) : (f32x2){__uint_as_float(yw << 16), __uint_as_float(yw & 0xffff0000u)};
               const f32x2 z = pk_fma(yy, (f32x2){c0[0], c1[0]}, (f32x2){c0[1], c1[1]});
               f32x2 gp;
               if (GELU || fz.eact == MC_ACT_GELU) gp = gelu_grad_poly2(z);
@@ -296,7 +311,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #pragma unroll
             // normalise on load.  (A/B on MI355X: the packed-f32 FMA form, 207 us at level 0, beats a single-issue-FMA form
             // with twice the instructions, 275-290 us: the loader waves are bound by instruction issue beside the MFMAs.)
-            for (int it = 0; it < PER; ++it) v[it] = xform_bf16x8(v[it], psc, psh, GELU ? (int)MC_ACT_GELU : pact);
+            for (int it = 0; it < PER; ++it)
+              v[it] = H16 ? xform_f16x8(v[it], psc, psh, GELU ? (int)MC_ACT_GELU : pact) : xform_bf16x8(v[it], psc, psh, GELU ? (int)MC_ACT_GELU : pact);
             if (okm[SET] != 0xffffffffu) {                  // zero padding stays zero (border tiles of zero-padded layers only)
 #pragma unroll
               for (int it = 0; it < PER; ++it) if (!((okm[SET] >> it) & 1u)) v[it] = make_uint4(0, 0, 0, 0);
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #pragma unroll
       for (int kappa = S::kmin(T); kappa <= S::kmax(T); ++kappa) {
         const int r = i - kappa;
-        if (r >= 0 && r < RR_R) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S::fidx(T, kappa)], fr[k & 3], acc[r], 0, 0, 0);
+        if (r >= 0 && r < RR_R) acc[r] = rr_mfma<(H16 && FUSE != 2)>(wf[S::fidx(T, kappa)], fr[k & 3], acc[r]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -515,8 +531,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
               s1[0] += b01; s1[1] += b23;
               s2[0] = pk_fma(b01, b01, s2[0]); s2[1] = pk_fma(b23, b23, s2[1]);
             }
-            const auto sx = __builtin_amdgcn_permlane16_swap(pk_bf16(a01.x, a01.y), pk_bf16(b01.x, b01.y), false, false);
-            const auto sy = __builtin_amdgcn_permlane16_swap(pk_bf16(a23.x, a23.y), pk_bf16(b23.x, b23.y), false, false);
+            const auto sx = __builtin_amdgcn_permlane16_swap(rr_pk<H16>(a01.x, a01.y), rr_pk<H16>(b01.x, b01.y), false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(rr_pk<H16>(a23.x, a23.y), rr_pk<H16>(b23.x, b23.y), false, false);
 #ifdef MC_RR_NOSTORE   /* timing-only ablation: wrong results */
             if ((FULL || (colok && ty0 + r + (gq & 1) < g.Ho)) && sx[0] == 0x12345678u)
 #else
@@ -578,7 +594,7 @@ bool mc_rr_applies(int dtype, int cout, int wo, bool full_pad) {
   // the layer: the 64-wide tiles then waste up to a whole tile column, which the wide-tile kernel's 16 / 32-wide tiles do not
   // (A/B on MI355X, CFG-3 step, mixed / bf16: 0: 12.16 / 10.74 ms, 140: 12.12 / 10.70, 270: 12.32 / 10.86, 520: 12.62 / 11.18)
   static const int minw_full = [] { const char* e = getenv("MC_RR_MINW_DGRAD"); return e ? atoi(e) : 140; }();
-  if (!on || dtype != MC_BF16) return false;
+  if (!on || !mc_is16(dtype)) return false;
   if (full_pad && minw_full > 0 && wo < minw_full) return false;
   if (ntiles % 2 == 1) return true;
   return on >= 2 && ntiles <= 8 && wo >= minw;
@@ -605,7 +621,8 @@ int mc_rr_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hipSt
   const size_t total = (size_t)chunks * ntiles * nfrag * 64 * 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_pack_rr, dim3(blocks), dim3(256), 0, s, g, w, dgrad, (bf16_t*)packed, ntiles, total);
+  hipLaunchKernelGGL(k_pack_rr, dim3(blocks), dim3(256), 0, s, g, w, dgrad, (bf16_t*)packed, ntiles, total,
+                     (g.dtype == MC_MIX16 && !dgrad) ? 1 : 0);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -615,14 +632,14 @@ const char* mc_rr_kernel_name(const ConvGeom& g, int fuse) {
   return g.out_f32 ? "k_conv_rr_bf16<3,f32out>" : (fuse == 2 ? "k_conv_rr_bf16<3,dz>" : (fuse == 1 ? "k_conv_rr_bf16<3,norm>" : "k_conv_rr_bf16<3>"));
 }
 
-template <int K, int FUSE, bool F32, bool GELU>
+template <int K, int FUSE, bool F32, bool GELU, bool H16 = false>
 static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
                      float* part, const ConvFuse& fz, hipStream_t s) {
   using S = RR<K>;
   const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (FUSE == 2 ? (size_t)RR_R * RR_TW * 64 : (size_t)2 * S::NFRAG * 1024);
   static bool attr_set = false;                              // one per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU, H16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -632,7 +649,7 @@ static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const vo
   static const int cap_total = [] { const char* e = getenv("MC_RR_CAP"); return e ? atoi(e) : 256; }();   // one work-group per CU
   int cap = cap_total / groups > 0 ? cap_total / groups : 1;
   const int bx = items < cap ? items : cap;
-  hipLaunchKernelGGL((k_conv_rr_bf16<K, FUSE, F32, GELU>), dim3(bx, groups, 1), dim3(512), lds, s, g, (const bf16_t*)x0,
+  hipLaunchKernelGGL((k_conv_rr_bf16<K, FUSE, F32, GELU, H16>), dim3(bx, groups, 1), dim3(512), lds, s, g, (const bf16_t*)x0,
                      (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, fz);
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -646,16 +663,20 @@ int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* 
   const bool gelu = fuse == 2 ? fz.eact == MC_ACT_GELU
                               : ((fz.act0 == MC_ACT_GELU || (fz.act0 == MC_ACT_NONE && !fz.coef0)) &&
                                  (fz.act1 == MC_ACT_GELU || (fz.act1 == MC_ACT_NONE && !fz.coef1)));
-#define RRL(K, FU, F32, GE) rr_launch<K, FU, F32, GE>(g, x0, x1, bank, bias, y0, y1, part, fz, s)
-#define RRK(K)                                                                                                  \
+  // h16: MC_MIX16 forward launch (f16 operands), or an input-gradient launch whose epilogue reads an f16 y (fz.ey16)
+  const bool h16 = fuse == 2 ? fz.ey16 != 0 : g.dtype == MC_MIX16;
+  if (h16 && g.out_f32 == 2) return MC_EUNSUPPORTED;                  // (the split bf16 pair is a bf16-mode output form)
+#define RRL(K, FU, F32, GE, H) rr_launch<K, FU, F32, GE, H>(g, x0, x1, bank, bias, y0, y1, part, fz, s)
+#define RRK(K, H)                                                                                               \
   do {                                                                                                          \
-    if (fuse == 0) return g.out_f32 ? RRL(K, 0, true, true) : RRL(K, 0, false, true);                           \
-    if (fuse == 2) return gelu ? RRL(K, 2, false, true) : RRL(K, 2, false, false);                              \
-    if (g.out_f32) return gelu ? RRL(K, 1, true, true) : RRL(K, 1, true, false);                                \
-    return gelu ? RRL(K, 1, false, true) : RRL(K, 1, false, false);                                             \
+    if (fuse == 0) return g.out_f32 ? RRL(K, 0, true, true, H) : RRL(K, 0, false, true, H);                     \
+    if (fuse == 2) return gelu ? RRL(K, 2, false, true, H) : RRL(K, 2, false, false, H);                        \
+    if (g.out_f32) return gelu ? RRL(K, 1, true, true, H) : RRL(K, 1, true, false, H);                          \
+    return gelu ? RRL(K, 1, false, true, H) : RRL(K, 1, false, false, H);                                       \
   } while (0)
-  if (g.K == 5) RRK(5);
-  RRK(3);
+  if (h16) { if (g.K == 5) RRK(5, true); RRK(3, true); }
+  if (g.K == 5) RRK(5, false);
+  RRK(3, false);
 #undef RRK
 #undef RRL
 }

@@ -496,8 +496,9 @@ static int gkind_of(const mc_grad_src& g0, const mc_grad_src& g1) {
   return 0;
 }
 
-template <typename T, int GK>
-__global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __restrict__ y, mc_grad_src g0,
+// TY: storage type of y (MC_MIX16: y is f16 while the gradient tensors T are bf16)
+template <typename T, int GK, typename TY = T>
+__global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const TY* __restrict__ y, mc_grad_src g0,
                                                        mc_grad_src g1, float* __restrict__ part, int CP) {
   const int n = (int)blockIdx.z, cb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   float sc[8], sh[8], mean[8], rstd[8];
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256, 6) void k_gn_bwd_reduce(GnArgs a, const T* __r
       const int ry = i / a.W, xx = i - ry * a.W, yy = blk + ry * nblk;
 #pragma unroll
       for (int j = 0; j < 8; ++j) da[u][j] = 0.f;
-      V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v[u]);
+      V8<TY>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v[u]);
       grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da[u]);
       grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da[u]);
     }
@@ -652,8 +653,8 @@ __global__ __launch_bounds__(1024) void k_gn_bwd_finalize(const float* __restric
 }
 
 // phase 3: dy = rstd (dz gamma - m1 - yhat m2)   (GN)   |   dy = da act'(y)   (act only)
-template <typename T, int GK = 0>
-__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restrict__ y, const float* __restrict__ m12,
+template <typename T, int GK = 0, typename TY = T>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const TY* __restrict__ y, const float* __restrict__ m12,
                                                       mc_grad_src g0, mc_grad_src g1, T* __restrict__ dy, int rows_pb) {
   const int n = (int)blockIdx.z, cb = blockIdx.y;
   float sc[8], sh[8], mean[8], rstd[8], ga[8], m1[8], m2[8];
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
     const int ry = i / a.W, xx = i - ry * a.W, yy = y0 + ry;
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
     size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
-    V8<T>::ld(y + idx, v);
+    V8<TY>::ld(y + idx, v);
     grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
     grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
     float gz[8];
@@ -711,8 +712,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const T* __restr
 // data: they are bound by launch latency, not by bytes.  Needs every group inside one channel block (channels per group
 // 1, 2, 4 or 8).  The per-(sample, channel) sums go to `pc` [N][CP][2]; k_gn_param_grads adds them to dgamma / dbeta in sample
 // order for all such layers at the end of the backward pass.
-template <typename T, int GK>
-__global__ __launch_bounds__(1024) void k_gn_bwd_small(GnArgs a, const T* __restrict__ y, mc_grad_src g0, mc_grad_src g1,
+template <typename T, int GK, typename TY = T>
+__global__ __launch_bounds__(1024) void k_gn_bwd_small(GnArgs a, const TY* __restrict__ y, mc_grad_src g0, mc_grad_src g1,
                                                        T* __restrict__ dy, float* __restrict__ pc, int CP) {
   const int n = (int)blockIdx.y, cb = blockIdx.x;
   float sc[8], sh[8], mean[8], rstd[8], ga[8];
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(1024) void k_gn_bwd_small(GnArgs a, const T* __rest
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int yy = i / a.W, xx = i - yy * a.W;
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gz[8];
-    V8<T>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
+    V8<TY>::ld(y + cb8_index(n, cb, yy, xx, a.C8, a.H, a.W), v);
     grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
     grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
     act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(1024) void k_gn_bwd_small(GnArgs a, const T* __rest
     const int yy = i / a.W, xx = i - yy * a.W;
     float v[8], da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gz[8], o[8];
     const size_t idx = cb8_index(n, cb, yy, xx, a.C8, a.H, a.W);
-    V8<T>::ld(y + idx, v);
+    V8<TY>::ld(y + idx, v);
     grad_fetch_add<T, GKinds<GK>::k0>(g0, n, cb, yy, xx, a.C8, da);
     grad_fetch_add<T, GKinds<GK>::k1>(g1, n, cb, yy, xx, a.C8, da);
     act_bwd8<FastMath<T>::value>(v, sc, sh, a.act, gz);
@@ -863,9 +864,9 @@ __global__ void k_fold_padded(T* __restrict__ buf, int C8, int H, int W, int p, 
 // input-gradient kernel's epilogue): EVERY frame pixel (within p + 1 of the border; `all`: every pixel) gets its halo
 // sources added, is turned into dz in place and contributes to this block's (sum dz, sum dz * yhat) partials
 // part[n][stride][CP][2] at slot first + blockIdx.x.  With zero padding there is nothing to fold and no frame.
-template <typename T>
+template <typename T, typename TY = T>
 __global__ __launch_bounds__(256) void k_fold_padded_dz(T* __restrict__ buf, int C8, int H, int W, int p, int mode, int all,
-                                                        const T* __restrict__ y, const float* __restrict__ coef4, int act,
+                                                        const TY* __restrict__ y, const float* __restrict__ coef4, int act,
                                                         float* __restrict__ part, int stride, int first) {
   const int n = blockIdx.z, cb = blockIdx.y;
   const int t = p + 1;
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void k_fold_padded_dz(T* __restrict__ buf, int
         for (int j = 0; j < 8; ++j) acc[j] += v[j];
       }
     float yv[8], gz[8];
-    V8<T>::ld(y + cb8_index(n, cb, yy, xx, C8, H, W), yv);
+    V8<TY>::ld(y + cb8_index(n, cb, yy, xx, C8, H, W), yv);
     act_bwd8<FastMath<T>::value>(yv, sc, sh, act, gz);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -934,8 +935,8 @@ __global__ __launch_bounds__(256) void k_fold_padded_dz(T* __restrict__ buf, int
 
 // GroupNorm backward, last phase, from dz (see mc_gn_bwd_apply_dz): dy = scale dz - rstd (m1 + yhat m2); coef4 == NULL
 // (activation-only layer): dy = dz.  Rows x columns flattened like k_gn_bwd_apply.
-template <typename T, int GK>
-__global__ __launch_bounds__(256) void k_gn_bwd_apply_dz(mc_grad_src gs, const T* __restrict__ y, int C, int C8, int H, int W,
+template <typename T, int GK, typename TY = T>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply_dz(mc_grad_src gs, const TY* __restrict__ y, int C, int C8, int H, int W,
                                                          int groups, const float* __restrict__ coef4,
                                                          const float* __restrict__ m12, T* __restrict__ dy, int rows_pb) {
   const int n = blockIdx.z, cb = blockIdx.y;
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply_dz(mc_grad_src gs, const T
     const int ry = i / W, xx = i - ry * W, yy = y0 + ry;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dz[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
     const size_t idx = cb8_index(n, cb, yy, xx, C8, H, W);
-    if (coef4) V8<T>::ld(y + idx, v);
+    if (coef4) V8<TY>::ld(y + idx, v);
     grad_fetch_add<T, GK>(gs, n, cb, yy, xx, C8, dz);
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
@@ -1000,10 +1001,9 @@ __device__ __forceinline__ void bicubic_direct(const T* __restrict__ x, int n, i
       V8<T>::ld(x + cb8_index(n, cb, ys, ix[xo * 4 + b], C8, Hi, Wi), v);
       if (act >= 0) {
         act_fwd8<FastMath<T>::value>(v, sc, sh, act, v);
-        if (sizeof(T) == 2) {                              // the staged window holds the activation in the storage type
+        // the staged window holds the activation in the storage type
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = bf2f(f2bf(v[j]));
-        }
+        for (int j = 0; j < 8; ++j) v[j] = round_storage<T>(v[j]);
       }
       float w = wa * wx[xo * 4 + b];
 #pragma unroll
@@ -1017,6 +1017,11 @@ template <typename T> struct XformRaw;
 template <> struct XformRaw<bf16_t> {
   static __device__ __forceinline__ void apply(uint4 (&r)[1], const float (&sc)[8], const float (&sh)[8], int act) {
     r[0] = xform_bf16x8(r[0], sc, sh, act);
+  }
+};
+template <> struct XformRaw<f16_t> {
+  static __device__ __forceinline__ void apply(uint4 (&r)[1], const float (&sc)[8], const float (&sh)[8], int act) {
+    r[0] = xform_f16x8(r[0], sc, sh, act);
   }
 };
 template <> struct XformRaw<float> {
@@ -1467,6 +1472,7 @@ int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h,
   size_t total = (size_t)n * ((c + 7) / 8) * h * (w + 2 * pad_w);
   if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_nchw<float>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (float*)out, (float*)nullptr);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (bf16_t*)out, (bf16_t*)nullptr);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_pack_nchw<f16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (f16_t*)out, (f16_t*)nullptr);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1490,6 +1496,7 @@ int mc_unpack_nchw(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, in
   size_t total = (size_t)n * ((c + 7) / 8) * h * (w - 2 * crop_w);
   if (dtype == MC_F32) hipLaunchKernelGGL(k_unpack_nchw<float>, grid1(total), dim3(256), 0, s, (const float*)x, n, c, h, w, crop_w, mean_nc, out);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_unpack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, (const bf16_t*)x, n, c, h, w, crop_w, mean_nc, out);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_unpack_nchw<f16_t>, grid1(total), dim3(256), 0, s, (const f16_t*)x, n, c, h, w, crop_w, mean_nc, out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1501,7 +1508,7 @@ int mc_pack_grad_nchw(const float* g, int32_t n, int32_t c, int32_t h, int32_t w
   hipStream_t s = (hipStream_t)stream;
   size_t total = (size_t)n * ((c + 7) / 8) * h * w;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_grad_nchw<float>, grid1(total), dim3(256), 0, s, g, n, c, h, w, crop_w, mean_nc, (float*)out);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_grad_nchw<bf16_t>, grid1(total), dim3(256), 0, s, g, n, c, h, w, crop_w, mean_nc, (bf16_t*)out);
+  else if (mc_is16(dtype)) hipLaunchKernelGGL(k_pack_grad_nchw<bf16_t>, grid1(total), dim3(256), 0, s, g, n, c, h, w, crop_w, mean_nc, (bf16_t*)out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1522,6 +1529,7 @@ int mc_gn_partials(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_gn_partials<float>, g, dim3(256), 0, s, (const float*)y, C8, h, w, tiles, part);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_partials<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)y, C8, h, w, tiles, part);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_gn_partials<f16_t>, g, dim3(256), 0, s, (const f16_t*)y, C8, h, w, tiles, part);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1576,6 +1584,7 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
 #define GN_LAUNCH(T, P) hipLaunchKernelGGL((k_gn_act_fwd<T, P>), g, dim3(256), 0, s, a, (const T*)y, (T*)a_out, (T*)pooled)
   if (dtype == MC_F32) { if (pool == 1) GN_LAUNCH(float, 1); else if (pool == 2) GN_LAUNCH(float, 2); else GN_LAUNCH(float, 4); }
   else if (dtype == MC_BF16) { if (pool == 1) GN_LAUNCH(bf16_t, 1); else if (pool == 2) GN_LAUNCH(bf16_t, 2); else GN_LAUNCH(bf16_t, 4); }
+  else if (dtype == MC_MIX16) { if (pool == 1) GN_LAUNCH(f16_t, 1); else if (pool == 2) GN_LAUNCH(f16_t, 2); else GN_LAUNCH(f16_t, 4); }
   else return MC_EUNSUPPORTED;
 #undef GN_LAUNCH
   MC_CHECK_LAUNCH();
@@ -1631,6 +1640,7 @@ int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, in
   dim3 g = grid3((h / f) * (w / f), C8, n, 256, 4096);
   if (dtype == MC_F32) hipLaunchKernelGGL(k_avgpool<float>, g, dim3(256), 0, s, (const float*)x, C8, h, w, f, (float*)out);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_avgpool<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, h, w, f, (bf16_t*)out);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_avgpool<f16_t>, g, dim3(256), 0, s, (const f16_t*)x, C8, h, w, f, (f16_t*)out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1675,10 +1685,14 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
   hipStream_t s = (hipStream_t)stream;
   const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
 #define RED(T, GK) hipLaunchKernelGGL((k_gn_bwd_reduce<T, GK>), g, dim3(256), 0, s, a, (const T*)y, s0, s1, partials, a.C8 * 8)
+#define REDH(GK) hipLaunchKernelGGL((k_gn_bwd_reduce<bf16_t, GK, f16_t>), g, dim3(256), 0, s, a, (const f16_t*)y, s0, s1, partials, a.C8 * 8)
   if (dtype == MC_F32) RED(float, 0);
   else if (dtype == MC_BF16) {
     switch (gkind_of(s0, s1)) { case 1: RED(bf16_t, 1); break; case 2: RED(bf16_t, 2); break; case 3: RED(bf16_t, 3); break; default: RED(bf16_t, 0); }
+  } else if (dtype == MC_MIX16) {
+    switch (gkind_of(s0, s1)) { case 1: REDH(1); break; case 2: REDH(2); break; case 3: REDH(3); break; default: REDH(0); }
   } else return MC_EUNSUPPORTED;
+#undef REDH
 #undef RED
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1707,10 +1721,14 @@ int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   hipStream_t s = (hipStream_t)stream;
   const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
 #define APP(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply<T, GK>), g, dim3(256), 0, s, a, (const T*)y, m12, s0, s1, (T*)dy, rows)
+#define APPH(GK) hipLaunchKernelGGL((k_gn_bwd_apply<bf16_t, GK, f16_t>), g, dim3(256), 0, s, a, (const f16_t*)y, m12, s0, s1, (bf16_t*)dy, rows)
   if (dtype == MC_F32) APP(float, 0);
   else if (dtype == MC_BF16) {
     switch (gkind_of(s0, s1)) { case 1: APP(bf16_t, 1); break; case 2: APP(bf16_t, 2); break; case 3: APP(bf16_t, 3); break; default: APP(bf16_t, 0); }
+  } else if (dtype == MC_MIX16) {
+    switch (gkind_of(s0, s1)) { case 1: APPH(1); break; case 2: APPH(2); break; case 3: APPH(3); break; default: APPH(0); }
   } else return MC_EUNSUPPORTED;
+#undef APPH
 #undef APP
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1730,6 +1748,7 @@ int mc_gn_act_fwd_small(const void* y, const float* stat_partials, int32_t tiles
 #define FS(T, P) hipLaunchKernelGGL((k_gn_act_small<T, P>), g, dim3(1024), 0, s, a, (const T*)y, stat_partials, tiles, eps, stats_out, (T*)a_out, (T*)pooled)
   if (dtype == MC_F32) { if (pool == 1) FS(float, 1); else FS(float, 2); }
   else if (dtype == MC_BF16) { if (pool == 1) FS(bf16_t, 1); else FS(bf16_t, 2); }
+  else if (dtype == MC_MIX16) { if (pool == 1) FS(f16_t, 1); else FS(f16_t, 2); }
   else return MC_EUNSUPPORTED;
 #undef FS
   MC_CHECK_LAUNCH();
@@ -1750,10 +1769,14 @@ int mc_gn_act_bwd_small(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
   const int CP = a.C8 * 8;
 #define SM(T, GK) hipLaunchKernelGGL((k_gn_bwd_small<T, GK>), g, dim3(1024), 0, s, a, (const T*)y, s0, s1, (T*)dy, chan_sums, CP)
+#define SMH(GK) hipLaunchKernelGGL((k_gn_bwd_small<bf16_t, GK, f16_t>), g, dim3(1024), 0, s, a, (const f16_t*)y, s0, s1, (bf16_t*)dy, chan_sums, CP)
   if (dtype == MC_F32) SM(float, 0);
   else if (dtype == MC_BF16) {
     switch (gkind_of(s0, s1)) { case 1: SM(bf16_t, 1); break; case 2: SM(bf16_t, 2); break; case 3: SM(bf16_t, 3); break; default: SM(bf16_t, 0); }
+  } else if (dtype == MC_MIX16) {
+    switch (gkind_of(s0, s1)) { case 1: SMH(1); break; case 2: SMH(2); break; case 3: SMH(3); break; default: SMH(0); }
   } else return MC_EUNSUPPORTED;
+#undef SMH
 #undef SM
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1789,7 +1812,7 @@ int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int3
   dim3 g(cdiv(total, 256), C8, n);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded<float>, g, dim3(256), 0, s, (float*)buf, C8, hs, ws, pad, pad_mode, all);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_fold_padded<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all);
+  else if (mc_is16(dtype)) hipLaunchKernelGGL(k_fold_padded<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1823,6 +1846,7 @@ int mc_fold_padded_dz(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, i
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded_dz<float>, g, dim3(256), 0, s, (float*)buf, C8, hs, ws, pad, pad_mode, all, (const float*)y, coef, act, partials, part_stride_blocks, part_first_block);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_fold_padded_dz<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all, (const bf16_t*)y, coef, act, partials, part_stride_blocks, part_first_block);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL((k_fold_padded_dz<bf16_t, f16_t>), g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all, (const f16_t*)y, coef, act, partials, part_stride_blocks, part_first_block);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1842,6 +1866,11 @@ int mc_gn_bwd_apply_dz(const mc_grad_src* dz, const void* y, int32_t n, int32_t 
 #define APZ(T, GK) hipLaunchKernelGGL((k_gn_bwd_apply_dz<T, GK>), g, dim3(256), 0, s, *dz, (const T*)y, c, C8, h, w, gr, coef, m12, (T*)dy, rows)
   if (dtype == MC_F32) { if (dz->kind == MC_GSRC_PADFOLD) APZ(float, MC_GSRC_PADFOLD); else APZ(float, MC_GSRC_PLAIN); }
   else if (dtype == MC_BF16) { if (dz->kind == MC_GSRC_PADFOLD) APZ(bf16_t, MC_GSRC_PADFOLD); else APZ(bf16_t, MC_GSRC_PLAIN); }
+  else if (dtype == MC_MIX16) {
+#define APZH(GK) hipLaunchKernelGGL((k_gn_bwd_apply_dz<bf16_t, GK, f16_t>), g, dim3(256), 0, s, *dz, (const f16_t*)y, c, C8, h, w, gr, coef, m12, (bf16_t*)dy, rows)
+    if (dz->kind == MC_GSRC_PADFOLD) APZH(MC_GSRC_PADFOLD); else APZH(MC_GSRC_PLAIN);
+#undef APZH
+  }
   else return MC_EUNSUPPORTED;
 #undef APZ
   MC_CHECK_LAUNCH();
@@ -1858,6 +1887,7 @@ int mc_rect_copy(const void* src, int32_t hs, int32_t ws, int32_t sy, int32_t sx
   dim3 g(max(1, min(cdiv(rh * rw, 256), 512)), C8, n);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_rect_copy<float>, g, dim3(256), 0, s, (const float*)src, hs, ws, sy, sx, (float*)dst, hd, wd, dy, dx, rh, rw, C8, accumulate);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_rect_copy<f16_t>, g, dim3(256), 0, s, (const f16_t*)src, hs, ws, sy, sx, (f16_t*)dst, hd, wd, dy, dx, rh, rw, C8, accumulate);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_rect_copy<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, hs, ws, sy, sx, (bf16_t*)dst, hd, wd, dy, dx, rh, rw, C8, accumulate);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
@@ -1878,10 +1908,10 @@ int mc_concat_cb8(const void* const* srcs, const int32_t* src_c, int32_t n_src, 
   }
   t.first[n_src] = C8;
   hipStream_t s = (hipStream_t)stream;
-  const int per = h * w * (dtype == MC_F32 ? 2 : 1);
+  const int per = h * w * (dtype == MC_F32 ? 2 : 1);          // (16-bit types: a plain copy of 16-byte pieces)
   dim3 g(max(1, min(cdiv(per, 256 * 4), 1024)), C8, n);
   if (dtype == MC_F32) hipLaunchKernelGGL(k_concat_cb8<float>, g, dim3(256), 0, s, t, C8, h * w, (float*)out);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_concat_cb8<bf16_t>, g, dim3(256), 0, s, t, C8, h * w, (bf16_t*)out);
+  else if (mc_is16(dtype)) hipLaunchKernelGGL(k_concat_cb8<bf16_t>, g, dim3(256), 0, s, t, C8, h * w, (bf16_t*)out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1896,7 +1926,7 @@ int mc_gsrc_sum(const mc_grad_src* g0, const mc_grad_src* g1, int32_t n, int32_t
   dim3 g(max(1, min(cdiv(h * w, 256 * 4), 1024)), C8, n);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_gsrc_sum<float>, g, dim3(256), 0, s, gsrc_or_none(g0), gsrc_or_none(g1), C8, h, w, (float*)out);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_gsrc_sum<bf16_t>, g, dim3(256), 0, s, gsrc_or_none(g0), gsrc_or_none(g1), C8, h, w, (bf16_t*)out);
+  else if (mc_is16(dtype)) hipLaunchKernelGGL(k_gsrc_sum<bf16_t>, g, dim3(256), 0, s, gsrc_or_none(g0), gsrc_or_none(g1), C8, h, w, (bf16_t*)out);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1915,6 +1945,7 @@ int mc_bicubic_fwd_act(const void* x, const float* coef, int32_t act, int32_t n,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_fwd<float>, g, dim3(256), 0, s, (const float*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (float*)out, tiles_x, coef, a);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_fwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (bf16_t*)out, tiles_x, coef, a);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_bicubic_fwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (f16_t*)out, tiles_x, coef, a);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -1942,7 +1973,7 @@ int mc_bicubic_bwd_taps(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi,
 #define BW(T, A, B) hipLaunchKernelGGL((k_bicubic_bwd<T, A, B>), g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (T*)dx, tiles_x)
 #define BWT(T) do { if (y8 && x8) BW(T, 8, 8); else if (y8) BW(T, 8, 12); else if (x8) BW(T, 12, 8); else BW(T, 12, 12); } while (0)
   if (dtype == MC_F32) BWT(float);
-  else if (dtype == MC_BF16) BWT(bf16_t);
+  else if (mc_is16(dtype)) BWT(bf16_t);
   else return MC_EUNSUPPORTED;
 #undef BWT
 #undef BW
@@ -1969,7 +2000,7 @@ int mc_bicubic_bwd_separable(const mc_grad_src* gs, int32_t n, int32_t c, int32_
   if (dtype == MC_F32) {
     hipLaunchKernelGGL(k_bicubic_bwd_ypass<float>, g1, dim3(256), 0, s, *gs, C8, hi, wo, tys, tyj, tyw, ws);
     hipLaunchKernelGGL(k_bicubic_bwd_xpass<float>, g2, dim3(256), 0, s, ws, C8, hi, wi, wo, txs, txj, txw, (float*)dx);
-  } else if (dtype == MC_BF16) {
+  } else if (mc_is16(dtype)) {
     hipLaunchKernelGGL(k_bicubic_bwd_ypass<bf16_t>, g1, dim3(256), 0, s, *gs, C8, hi, wo, tys, tyj, tyw, ws);
     hipLaunchKernelGGL(k_bicubic_bwd_xpass<bf16_t>, g2, dim3(256), 0, s, ws, C8, hi, wi, wo, txs, txj, txw, (bf16_t*)dx);
   } else return MC_EUNSUPPORTED;

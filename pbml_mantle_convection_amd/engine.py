@@ -22,9 +22,11 @@ import torch
 
 from . import _lib as L
 
-# "mixed" = bf16 storage and MFMA arithmetic with the full-resolution level carried in split precision (Engine.split0)
+# "mixed" = MC_MIX16: every tensor of the forward pass in f16 (11 significant bits: what the momentum residual's second
+# differences need), every gradient tensor in bf16 (range), MFMA arithmetic with f32 accumulation; "split" = round 2's form
+# of the same idea (bf16 everywhere, the full-resolution level of the forward pass as bf16 (hi, lo) pairs: Engine.split0)
 DTYPES = {"fp32": (L.MC_F32, torch.float32), "f32": (L.MC_F32, torch.float32),
-          "bf16": (L.MC_BF16, torch.bfloat16), "mixed": (L.MC_BF16, torch.bfloat16)}
+          "bf16": (L.MC_BF16, torch.bfloat16), "mixed": (L.MC_MIX16, torch.float16), "split": (L.MC_BF16, torch.bfloat16)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -361,6 +363,8 @@ class Engine:
         self.g = graph
         self.precision = "fp32" if precision == "f32" else precision
         self.mc_dtype, self.t_dtype = DTYPES[precision]
+        # gradient tensors: bf16 in the "mixed" mode (their range), the forward type otherwise
+        self.mc_gdtype, self.g_dtype = (L.MC_BF16, torch.bfloat16) if self.mc_dtype == L.MC_MIX16 else (self.mc_dtype, self.t_dtype)
         self.shape = None
         self._tables = {}
         # filter-gradient kernels on a second stream: 0 = never, 1 = every layer, 2 = only layers of <= 128 x 128 pixels
@@ -385,7 +389,7 @@ class Engine:
         # two sources with its filters repeated (2 x the MFMA work of those layers; the backward pass is plain bf16).  The
         # momentum residual takes second differences x 126^2 of the output; with 8-bit storage at the full-resolution level
         # its value is rounding noise (2.0 x the exact value at 506^2, tests/study_bf16_momentum.py).
-        self.split0 = precision == "mixed"
+        self.split0 = precision == "split"
         # GroupNorm + activation of layers with at most this many pixels run as ONE launch per direction (statistics + apply
         # forward; reduce + finalize + apply backward).  MI355X, CFG-3: 64 x 64 and 32 x 32 layers 21 -> 11 us forward and
         # 38 -> 24 us backward; 128 x 128 layers break even (25 -> 24, 49 -> 53 us: 128 blocks do not fill the chip)
@@ -420,6 +424,9 @@ class Engine:
         def cb8(c, h, w):
             return torch.empty((N, (c + 7) // 8, h, w, 8), dtype=self.t_dtype, device=device)
 
+        def cb8g(c, h, w):                   # a gradient tensor
+            return torch.empty((N, (c + 7) // 8, h, w, 8), dtype=self.g_dtype, device=device)
+
         T[0].buf = cb8(T[0].C, T[0].H, T[0].W)
         # consumers of every tensor (decides which activated tensors need not be materialised)
         cons: Dict[int, list] = {tid: [] for tid in g.channels}
@@ -443,7 +450,7 @@ class Engine:
                 o.H, o.W = ho, wo
                 o.buf = cb8(o.C, ho, wo)
                 tabs = (self._table(s.H, ho), self._table(s.W, wo))
-                e = dict(node=node, tabs=tabs, dsrc=cb8(s.C, s.H, s.W),
+                e = dict(node=node, tabs=tabs, dsrc=cb8g(s.C, s.H, s.W),
                          maxtaps=tuple(int(np.diff(bicubic_tables(a, b)[2]).max()) for a, b in ((s.H, ho), (s.W, wo))))
                 if ho > 3 * s.H or wo > 3 * s.W:
                     # scale factor > 3: the adjoint runs as two 1-D passes through an f32 workspace (tap lists too long
@@ -456,7 +463,7 @@ class Engine:
                 o.H, o.W = s.H // node.f, s.W // node.f
                 o.buf = cb8(o.C, o.H, o.W)
                 o.requires_grad = s.requires_grad
-                self.plan.append(dict(node=node, dsum=cb8(o.C, o.H, o.W)))
+                self.plan.append(dict(node=node, dsum=cb8g(o.C, o.H, o.W)))
                 continue
             if node.kind == "cat":
                 srcs = [T[i] for i in node.srcs]
@@ -472,11 +479,11 @@ class Engine:
             for s in srcs:
                 assert (s.H, s.W) == (h, w), "concat sources must agree in size"
             if node.learned:
-                self.plan.append(self._plan_learned(node, srcs, T, cb8, f32, N, device))
+                self.plan.append(self._plan_learned(node, srcs, T, cb8, cb8g, f32, N, device))
                 e = self.plan[-1]
                 max_dy = max(max_dy, N * e["coutp"] * T[node.out].H * T[node.out].W)
                 continue
-            final_f32 = (node.post == L.POST_NONE and node is g.nodes[-1] and self.mc_dtype == L.MC_BF16
+            final_f32 = (node.post == L.POST_NONE and node is g.nodes[-1] and self.mc_dtype != L.MC_F32
                          and node.c_out <= 16)
             ho, wo = h + 2 * node.pad - node.k + 1, w + 2 * node.pad - node.k + 1
             # raw output in f32, activation stored as a (hi, lo) bf16 pair: full-resolution conv + (GN) + act layers
@@ -506,7 +513,7 @@ class Engine:
             coutp = ((node.c_out + 7) // 8) * 8
             cin_tot = sum(s.C for s in srcs)
             # dgrad = the same kernel on the padded domain: zero pad k-1, rotated/transposed bank
-            dd = L.ConvDesc(N, ho, wo, node.c_out, 0, cin_tot, node.k, node.k - 1, 0, self.mc_dtype, 0,
+            dd = L.ConvDesc(N, ho, wo, node.c_out, 0, cin_tot, node.k, node.k - 1, 0, self.mc_gdtype, 0,
                             srcs[0].C if len(srcs) > 1 else 0, 0)
             need_dgrad = any(s.requires_grad for s in srcs)
             e = dict(node=node, desc=d, ddesc=dd, tiles=tiles, coutp=coutp,
@@ -572,7 +579,7 @@ class Engine:
                 e["dbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 1), dtype=torch.uint8,
                                          device=device)
                 hp, wp = h + 2 * node.pad, w + 2 * node.pad
-                e["dxp"] = [cb8(s.C, hp, wp) for s in srcs]
+                e["dxp"] = [cb8g(s.C, hp, wp) for s in srcs]
                 # GroupNorm-backward reduction fused into this launch's epilogue: the source is the full-resolution output
                 # of a conv + (GN) + act layer and this conv is its only consumer
                 pe = self.prod.get(node.srcs[0])
@@ -593,7 +600,7 @@ class Engine:
         self.T = T
         # two dY buffers: the filter gradient of layer L runs on a side stream while the main stream already
         # prepares dY of layer L-1 (see backward)
-        self.dYs = [torch.empty(max_dy, dtype=self.t_dtype, device=device) for _ in range(2)]
+        self.dYs = [torch.empty(max_dy, dtype=self.g_dtype, device=device) for _ in range(2)]
         self.dY = self.dYs[0]
         # ... or one dY buffer per layer (default): the main chain then never waits for the side stream, the captured step is one
         # linear chain plus a side chain with fork edges only, and the graph executor keeps the chain on one hardware queue
@@ -603,7 +610,7 @@ class Engine:
             for e in self.plan:
                 if e["node"].kind == "conv":
                     o = T[e["node"].out]
-                    e["dY"] = torch.empty(N * e["coutp"] * o.H * o.W, dtype=self.t_dtype, device=device)
+                    e["dY"] = torch.empty(N * e["coutp"] * o.H * o.W, dtype=self.g_dtype, device=device)
         self.convs = [e for e in self.plan if e["node"].kind == "conv" and not e["node"].learned]
         self.side = torch.cuda.Stream(device=device)
         # events of the two-stream backward, created once (none is created inside a graph capture)
@@ -614,7 +621,7 @@ class Engine:
         assert self.final_plain or not g.subtract_mean
         fo = T[last["node"].out]
         self.out_h, self.out_w = fo.H, fo.W - 2 * g.crop_w
-        self.dOut = None if self.final_plain else cb8(fo.C, fo.H, fo.W)
+        self.dOut = None if self.final_plain else cb8g(fo.C, fo.H, fo.W)
         self.chan_mean = torch.empty((N, g.c_out), **f32) if g.subtract_mean else None
         self.gmean = torch.empty((N, g.c_out), **f32) if g.subtract_mean else None
         self.shape = (N, H, W, str(device))
@@ -623,7 +630,7 @@ class Engine:
     LBANKS = ("conv", "conv_top_left", "conv_top_right", "conv_bottom_left", "conv_bottom_right", "conv_top", "conv_bottom",
               "conv_left", "conv_right")
 
-    def _plan_learned(self, node, srcs, T, cb8, f32, N, device):
+    def _plan_learned(self, node, srcs, T, cb8, cb8g, f32, N, device):
         """Nine bias-free valid convolutions on the library's conv kernels, the strips cut / the frame assembled with
         mc_rect_copy (reference pytorch_networks_convae.py:1022-1065).  The gradient w.r.t. the input needs no padded
         domain: the adjoint of a valid convolution is exactly input-sized."""
@@ -647,20 +654,20 @@ class Engine:
         for name, (sy, sx, sh, sw, dy, dx) in regs.items():
             d = L.ConvDesc(N, sh, sw, s.C, 0, node.c_out, k, 0, L.PAD_MODES["zeros"], self.mc_dtype, node.sym_h, 0, 0)
             rh, rw = sh - k + 1, sw - k + 1
-            dd = L.ConvDesc(N, rh, rw, node.c_out, 0, s.C, k, k - 1, 0, self.mc_dtype, 0, 0, 0)
+            dd = L.ConvDesc(N, rh, rw, node.c_out, 0, s.C, k, k - 1, 0, self.mc_gdtype, 0, 0, 0)
             if L.call("mc_conv_tiles", C.byref(d)) <= 0:
                 raise L.MantleHipError(f"unsupported convolution configuration for {node.name}{name}")
             u8 = dict(dtype=torch.uint8, device=device)
             banks[name] = dict(desc=d, ddesc=dd, reg=(sy, sx, sh, sw, dy, dx), rh=rh, rw=rw,
                                S=None if name == "conv" else cb8(s.C, sh, sw), R=cb8(node.c_out, rh, rw),
-                               dR=cb8(node.c_out, rh, rw), dS=cb8(s.C, sh, sw),
+                               dR=cb8g(node.c_out, rh, rw), dS=cb8g(s.C, sh, sw),
                                bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), **u8),
                                dbank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 1), **u8),
                                wpart=torch.empty(L.call("mc_wgrad_partial_bytes", C.byref(d)), **u8))
         coutp = ((node.c_out + 7) // 8) * 8
         tiles = min(64, ho)
         e = dict(node=node, banks=banks, tiles=tiles, coutp=coutp, Y=cb8(node.c_out, ho, wo),
-                 part=torch.empty((N, tiles, coutp, 2), **f32), need_dgrad=s.requires_grad, dxl=cb8(s.C, h, w), desc=None)
+                 part=torch.empty((N, tiles, coutp, 2), **f32), need_dgrad=s.requires_grad, dxl=cb8g(s.C, h, w), desc=None)
         o.buf = cb8(node.c_out, ho, wo) if node.post != L.POST_NONE else e["Y"]
         if node.post == L.POST_GN_ACT:
             e["stats"] = torch.empty((N, node.groups, 2), **f32)
@@ -699,7 +706,7 @@ class Engine:
         for name, b in e["banks"].items():                      # "conv" comes first: its input gradient initialises dxl
             sy, sx, sh, sw, dy, dx = b["reg"]
             L.call("mc_rect_copy", L.ptr(dY), o_h, o_w, dy, dx, L.ptr(b["dR"]), b["rh"], b["rw"], 0, 0, b["rh"], b["rw"], N, node.c_out,
-                   0, self.mc_dtype, st)
+                   0, self.mc_gdtype, st)
             xin = src.buf if b["S"] is None else b["S"]
             L.call("mc_conv2d_wgrad", C.byref(b["desc"]), L.ptr(xin), None, L.ptr(b["dR"]), L.ptr(b["wpart"]), st)
             L.call("mc_conv2d_wgrad_finalize", C.byref(b["desc"]), L.ptr(b["wpart"]), L.ptr(grads[node.name + name + ".weight"]),
@@ -711,7 +718,7 @@ class Engine:
                 L.call("mc_conv2d", C.byref(b["ddesc"]), L.ptr(b["dR"]), None, L.ptr(b["dbank"]), None, L.ptr(tgt), None, None, st)
                 if name != "conv":
                     L.call("mc_rect_copy", L.ptr(b["dS"]), sh, sw, 0, 0, L.ptr(e["dxl"]), src.H, src.W, sy, sx, sh, sw, N, src.C, 1,
-                           self.mc_dtype, st)
+                           self.mc_gdtype, st)
         if e["need_dgrad"]:
             src.gsrcs.append(L.GradSrc(L.ptr(e["dxl"]), L.GSRC_PLAIN, 0, 0, 1, src.H, src.W))
 
@@ -908,7 +915,7 @@ class Engine:
                    L.ptr(self.gmean), st)
             mean = self.gmean
         gdst = (self.plan[-1]["dY"] if self.dy_per_layer else self.dYs[0]) if self.final_plain else self.dOut
-        L.call("mc_pack_grad_nchw", L.ptr(gout), N, g.c_out, fo.H, fo.W, g.crop_w, L.ptr(mean), self.mc_dtype,
+        L.call("mc_pack_grad_nchw", L.ptr(gout), N, g.c_out, fo.H, fo.W, g.crop_w, L.ptr(mean), self.mc_gdtype,
                L.ptr(gdst), st)
         if not self.final_plain:
             fo.gsrcs.append(L.GradSrc(L.ptr(self.dOut), L.GSRC_PLAIN, 0, 0, 1, fo.H, fo.W))
@@ -938,7 +945,7 @@ class Engine:
                     s.gsrcs.append(L.GradSrc(q.ptr, L.GSRC_PADFOLD_POOL, q.pad, q.pad_mode, node.f, o.H, o.W))
                 else:
                     g1 = C.byref(o.gsrcs[1]) if len(o.gsrcs) > 1 else None
-                    L.call("mc_gsrc_sum", C.byref(q), g1, N, o.C, o.H, o.W, self.mc_dtype, L.ptr(e["dsum"]), st)
+                    L.call("mc_gsrc_sum", C.byref(q), g1, N, o.C, o.H, o.W, self.mc_gdtype, L.ptr(e["dsum"]), st)
                     s.gsrcs.append(L.GradSrc(L.ptr(e["dsum"]), L.GSRC_PLAIN_POOL, 0, 0, node.f, o.H, o.W))
                 continue
             if node.kind == "up":
@@ -947,10 +954,10 @@ class Engine:
                 (_, _, tys, tyj, tyw), (_, _, txs, txj, txw) = e["tabs"]
                 if "bws" in e:
                     L.call("mc_bicubic_bwd_separable", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
-                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_dtype, L.ptr(e["bws"]), L.ptr(e["dsrc"]), st)
+                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_gdtype, L.ptr(e["bws"]), L.ptr(e["dsrc"]), st)
                 else:
                     L.call("mc_bicubic_bwd_taps", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
-                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), e["maxtaps"][0], e["maxtaps"][1], self.mc_dtype,
+                           L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), e["maxtaps"][0], e["maxtaps"][1], self.mc_gdtype,
                            L.ptr(e["dsrc"]), st)
                 s.gsrcs.append(L.GradSrc(L.ptr(e["dsrc"]), L.GSRC_PLAIN, 0, 0, 1, s.H, s.W))
                 continue
@@ -1036,7 +1043,7 @@ class Engine:
                     pn, s0 = pe["node"], srcs[0]
                     coef = L.ptr(pe["coef"]) if pn.post == L.POST_GN_ACT else None
                     epi = L.ConvEpilogue(L.ptr(pe["Y"]), coef, act, node.pad, self.mode, s0.H, s0.W, L.ptr(pe["dz_part"]),
-                                         pe["dz_blocks"])
+                                         pe["dz_blocks"], int(self.mc_dtype == L.MC_MIX16))
                     self._probe_begin()
                     L.call("mc_conv2d_fused", C.byref(e["ddesc"]), L.ptr(dY), None, None, L.ptr(e["dbank"]), None,
                            L.ptr(dxp[0]), None, None, C.byref(epi), st)
@@ -1052,7 +1059,7 @@ class Engine:
                 for s, buf in zip(srcs, dxp):
                     if s.requires_grad:
                         # adjoint of the padding: fold the halo onto the interior once, consumers read at an offset
-                        L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_dtype, st)
+                        L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_gdtype, st)
                         s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(self.side)
         if gp_jobs:
@@ -1122,7 +1129,7 @@ class Engine:
     def _probe_end(self, d, label):
         if self._probe is not None:
             ev = self._probe_event()
-            es = torch.tensor([], dtype=self.t_dtype).element_size()
+            es = torch.tensor([], dtype=self.t_dtype).element_size()       # (forward and gradient tensors have the same width)
             ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
             cin = d.c_in0 + d.c_in1
             nbytes = d.n * es * (cin * d.h * d.w + d.c_out * ho * wo)          # algorithmic: read input once, write output once
@@ -1165,7 +1172,7 @@ class Engine:
 
     def algorithmic_bytes_per_sample(self, precision=None) -> float:
         """3 s (sum_in + sum_out over the conv layers) + s_io (C_i + 2 C_o) H W."""
-        s = 2 if (precision or self.precision) in ("bf16", "mixed") else 4
+        s = 2 if (precision or self.precision) in ("bf16", "mixed", "split") else 4
         tot = 0
         for e in self.plan:
             if e["node"].kind != "conv":
@@ -1177,7 +1184,9 @@ class Engine:
             d = e["desc"]
             ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
             tot += (d.c_in0 + d.c_in1) * d.h * d.w + d.c_out * ho * wo
-        return 3.0 * s * tot + 4.0 * (self.g.c_in + 2 * self.g.c_out) * self.out_h * self.out_w
+        # (s_io = s: SURVEY §8d prices the boundary tensors in the storage type as well; round 2 used 4 bytes here, which
+        # flattered hbm_roofline_frac_step by 1.7 %)
+        return 3.0 * s * tot + float(s) * (self.g.c_in + 2 * self.g.c_out) * self.out_h * self.out_w
 
     def activation_bytes(self) -> int:
         tot = 0

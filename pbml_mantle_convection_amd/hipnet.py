@@ -60,10 +60,11 @@ class HipNetMixin:
         return self._precision
 
     def set_precision(self, precision: str):
-        """'fp32' (parity gate: f32 storage and arithmetic), 'bf16' (bf16 storage, f32 accumulate) or 'mixed' (bf16 with the
-        full-resolution level of the forward pass in split precision: what the momentum residual needs, engine.py)."""
-        if precision not in ("fp32", "bf16", "mixed"):
-            raise ValueError("precision must be 'fp32', 'bf16' or 'mixed'")
+        """'fp32' (parity gate: f32 storage and arithmetic), 'bf16' (bf16 storage, f32 accumulate), 'mixed' (f16 tensors in
+        the forward pass, bf16 gradient tensors: what the momentum residual needs, engine.py) or 'split' (round 2's form of
+        'mixed': bf16 with the full-resolution level of the forward pass as bf16 (hi, lo) pairs)."""
+        if precision not in ("fp32", "bf16", "mixed", "split"):
+            raise ValueError("precision must be 'fp32', 'bf16', 'mixed' or 'split'")
         self._precision = precision
         return self
 
