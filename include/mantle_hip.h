@@ -262,6 +262,11 @@ int mc_gn_act_bwd_reduce(const void* y, int32_t n, int32_t c, int32_t h, int32_t
 int mc_gn_act_bwd_finalize(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups,
                            int32_t hw, const float* gamma, float* m12_ng2, float* dgamma, float* dbeta,
                            void* stream);
+/* The same for partial tables with many slots per sample (the input-gradient epilogue's): one block per (group, sample);
+ * writes m12 [n][groups][2] and the per-(sample, channel) sums chan_sums [n][c8*8][2]; dgamma / dbeta follow from
+ * mc_gn_param_grads_batched (samples in order: deterministic).  Channels per group: 1, 2, 4 or 8. */
+int mc_gn_act_bwd_finalize_n(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups, int32_t hw,
+                             const float* gamma, float* m12_ng2, float* chan_sums, void* stream);
 int mc_gn_act_bwd_apply(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
                         const float* stats_ng2, const float* m12_ng2, const float* gamma,
                         const float* beta, int32_t post, int32_t act, int32_t dtype,

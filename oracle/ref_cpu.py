@@ -85,6 +85,24 @@ def gelu_grad_bf16_mode(t: Tensor) -> Tensor:
     return _odd_poly(t, GELU_GRAD_POLY)
 
 
+# "mixed" mode, input-gradient epilogue of the wide layers (csrc/conv_rr_bf16.hip, epilogue_dz, packed-f16 form): GELU'(z) =
+# 1/2 + z Q4(z^2) on |z| <= 3 (clamped), every operation rounded to f16 (v_pk_fma_f16 rounds once per FMA).
+GELU_GRAD_POLY_F16 = (7.8907706e-01, -2.4320666e-01, 4.2797559e-02, -3.8080227e-03, 1.3422040e-04)
+
+
+def gelu_grad_f16_mode(t: Tensor) -> Tensor:
+    """The device's packed-f16 evaluation, emulated: inputs, coefficients and every FMA result rounded to f16."""
+    h = torch.float16
+    r16 = lambda v: v.to(torch.float32).to(h).to(torch.float64)  # noqa: E731
+    zc = r16(t.to(torch.float64)).clamp(-3.0, 3.0)
+    w = r16(zc * zc)
+    c = [float(torch.tensor(ck, dtype=h)) for ck in GELU_GRAD_POLY_F16]
+    q = torch.full_like(zc, c[-1])
+    for ck in c[-2::-1]:
+        q = r16(q * w + ck)
+    return r16(zc * q + 0.5).to(t.dtype)
+
+
 def torch_pad_mode(r_p: str) -> str:
     """'zeros' is spelled 'constant' for F.pad (pytorch_networks_convae.py:732-735)."""
     return "constant" if r_p == "zeros" else r_p

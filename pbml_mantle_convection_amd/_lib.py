@@ -92,6 +92,7 @@ SIGNATURES = {
     "mc_gn_act_bwd_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _GS,
                                        _GS, _vp, _vp]),
     "mc_gn_act_bwd_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mc_gn_act_bwd_finalize_n": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_gn_act_bwd_apply": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _GS, _GS, _vp, _vp]),
     "mc_gn_act_fwd_small": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,

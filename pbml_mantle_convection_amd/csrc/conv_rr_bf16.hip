@@ -75,16 +75,26 @@ template <bool H16> __device__ __forceinline__ uint32_t rr_pk(float a, float b) 
 //   filter fragments of a one-chunk layer are staged through it once, before its first use; several chunks (a rare
 //   shape): the MFMA waves fetch their fragments from global memory per stage.
 // GELU: every fused activation is GELU (inline polynomial); otherwise the generic activation switch is compiled in.
-template <int K, int FUSE, bool OUT_F32, bool GELU, bool H16 = false>
+template <int K, int FUSE, bool OUT_F32, bool GELU, bool H16 = false, bool DZM = false>
 __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
                                                          const bf16_t* __restrict__ bank, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y0, bf16_t* __restrict__ y1,
                                                          float* __restrict__ part, ConvFuse fz) {
   using S = RR<K>;
+  // FUSE == 2 comes in two forms.  DZM (MC_MIX16 layers with GELU: y is f16): the MFMA waves keep their accumulators and
+  // form dz and the two sums themselves in PACKED f16 (8.5 vector instructions per element); the loader waves run the plain
+  // schedule.  LEX (any other type / activation): the accumulators go to the loader waves through LDS (`exch`), which
+  // evaluate act' in f32 beside the next stage's MFMAs.  Round 3 measured the packed-f16 math on the LEX schedule too
+  // (level-0 16 -> 16: 293 us against 118 us for the plain input gradient): with the y loads and the dz stores on top of
+  // the window loads, FOUR loader waves issue every vector-memory instruction of the work-group (~200 cycles each while the
+  // memory pipeline is backed up) and the MFMA waves wait at the barrier three quarters of the time.
+  // DZM is instantiated for one-chunk launches only (<= 16 input channels of the launch: the host checks)
+  static_assert(!DZM || (FUSE == 2 && H16 && GELU), "the MFMA-side dz epilogue is the packed-f16 GELU form");
+  constexpr bool LEX = FUSE == 2 && !DZM;
   constexpr int TIH = S::TIH, TIW = S::TIW, PLANE = S::PLANE, NFRAG = S::NFRAG, NTY = S::NTYPES;
   constexpr int PER = (TIH * TIW + 255) / 256;            // staging slots per loader thread and plane
   constexpr int YSLOTS = RR_R * RR_TW, YPER = YSLOTS / 256;
-  constexpr int NW = FUSE == 2 ? 1 : 2;
+  constexpr int NW = LEX ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint4* const inbuf = reinterpret_cast<uint4*>(smem_raw);
   uint4* const wbuf = inbuf + 2 * 2 * PLANE;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
   const int my_items = (items - bid + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * chunks;
   if (total <= 0) return;                                   // (uniform: every wave of the work-group leaves)
-  const bool w_global = FUSE == 2 && chunks > 1;           // filter fragments straight from global memory (rare shape)
+  const bool w_global = LEX && chunks > 1;                 // filter fragments straight from global memory (rare shape)
 
   auto stage_coords = [&](int t, int& n, int& ty0, int& tx0, int& ck, int& tile) {
     const int jitem = t / chunks;
@@ -124,13 +134,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
       s_rc[it] = (live ? 0 : (1 << 31)) | (r << 15) | c;
       s_off[it] = (unsigned)(r * g.W + c) * 16u;
     }
-    v4u rin[2][2][PER];                                    // [register set][plane][slot]
+    // FUSE == 2 keeps ONE stage of loads in flight (issued before the long epilogue of the previous stage, committed after
+    // it); the other forms two (the loads of stage t + 2 are issued while stage t + 1 is delivered)
+    constexpr int NSET = LEX ? 1 : 2;
+    v4u rin[NSET][2][PER];                                 // [register set][plane][slot]
     unsigned okm[2] = {0xffffffffu, 0xffffffffu};
     v4u yv[2][YPER];                                       // FUSE == 2: the producer's raw output at this thread's pixels
     float ecv[4] = {1.f, 0.f, 0.f, 0.f};                   // FUSE == 2: (scale, shift, mean, rstd) of channel lane & 15 (four
                                                            // scalars: v_readlane of an ext-vector element returned element 0)
     constexpr int WPER = (NFRAG * 64 + 255) / 256;         // filter-fragment slots per loader thread
-    v4u wv[2][WPER];                                       // the stage's filter fragments (staged through LDS for the MFMA waves)
+    v4u wv[LEX ? 1 : 2][LEX ? 1 : WPER];       // the stage's filter fragments (staged through LDS for the MFMA waves)
     const bool w_every = !w_global && chunks > 1;          // several chunks: a fresh set per stage; one chunk: stage 0 only
 
     auto issue = [&](int t, auto set_c) {
@@ -172,15 +185,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
           rin[SET][cb][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         }
       }
-      if (!w_global && (w_every || t == 0)) {
-        const v4u* wsrc = reinterpret_cast<const v4u*>(bank) + (size_t)(ck * ntiles_total + grp) * NFRAG * 64;
+      if constexpr (!LEX) {
+        if (!w_global && (w_every || t == 0)) {
+          const v4u* wsrc = reinterpret_cast<const v4u*>(bank) + (size_t)(ck * ntiles_total + grp) * NFRAG * 64;
 #pragma unroll
-        for (int it = 0; it < WPER; ++it) wv[SET][it] = wsrc[min(tl + it * 256, NFRAG * 64 - 1)];
+          for (int it = 0; it < WPER; ++it) wv[SET][it] = wsrc[min(tl + it * 256, NFRAG * 64 - 1)];
+        }
       }
     };
     // FUSE == 2: y and the coefficients of stage t's work item, for the epilogue one iteration later
     auto load_y = [&](int t) {
-      if constexpr (FUSE == 2) {
+      if constexpr (LEX) {
         if ((t % chunks) != chunks - 1) return;
         int n, ty0, tx0, ck, tile;
         stage_coords(t, n, ty0, tx0, ck, tile);
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
     // FUSE == 2: epilogue of stage t from the accumulators the MFMA waves left in `exch`: dz = dA act'(z) for the pixels
     // whose value is final (raw dA otherwise), the per-wave (sum dz, sum dz yhat) partials, the stores
     auto epilogue_dz = [&](int t) {
-      if constexpr (FUSE == 2) {
+      if constexpr (LEX) {
         if ((t % chunks) != chunks - 1) return;
         int n, ty0, tx0, ck, tile;
         stage_coords(t, n, ty0, tx0, ck, tile);
@@ -323,10 +338,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         for (int it = 0; it < PER; ++it)
           if (s_rc[it] >= 0) dst[cb * PLANE + ((s_rc[it] >> 15) & 0x7fff) * TIW + (s_rc[it] & 0x7fff)] = v[it];
       }
-      if (!w_global && (w_every || t == 0)) {
-        v4u* wd = reinterpret_cast<v4u*>(wbuf) + (w_every ? (t & 1) : 0) * NFRAG * 64;
+      if constexpr (!LEX) {
+        if (!w_global && (w_every || t == 0)) {
+          v4u* wd = reinterpret_cast<v4u*>(wbuf) + (w_every ? (t & 1) : 0) * NFRAG * 64;
 #pragma unroll
-        for (int it = 0; it < WPER; ++it) if (tl + it * 256 < NFRAG * 64) wd[tl + it * 256] = wv[SET][it];
+          for (int it = 0; it < WPER; ++it) if (tl + it * 256 < NFRAG * 64) wd[tl + it * 256] = wv[SET][it];
+        }
       }
     };
     using S0 = std::integral_constant<int, 0>;
@@ -334,35 +351,65 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #ifdef MC_RR_STAMPS
     long long st_acc[4] = {0, 0, 0, 0}, st_prev = clock64();
 #endif
+    if constexpr (LEX) {
+      // one-chunk layers: the filter fragments pass through `exch` once (registers local to this block)
+      if (!w_global) {
+        const v4u* wsrc = reinterpret_cast<const v4u*>(bank) + (size_t)grp * NFRAG * 64;
+        v4u* wd = reinterpret_cast<v4u*>(wbuf);
+#pragma unroll
+        for (int it = 0; it < WPER; ++it) {
+          const v4u w = wsrc[min(tl + it * 256, NFRAG * 64 - 1)];
+          if (tl + it * 256 < NFRAG * 64) wd[tl + it * 256] = w;
+        }
+      }
+      issue(0, S0{});
+      commit(0, S0{});
+      __syncthreads();
+      // iteration t (the MFMA waves compute stage t): loads of stage t + 1 -> epilogue of stage t - 1 from `exch` (the long
+      // vector-ALU phase, beside the MFMAs) -> y of stage t -> delivery of stage t + 1.  Two barriers per stage: the MFMA
+      // waves write their accumulators to `exch` between them.
+      // (one extra trip for the last epilogue: a single call site keeps the unrolled epilogue once in the instruction stream)
+      for (int t = 0; t <= total; ++t) {
+        if (t + 1 < total) issue(t + 1, S0{});
+        RR_STAMP(3);
+        if (t > 0) epilogue_dz(t - 1);
+        if (t == total) break;
+        load_y(t);
+        RR_STAMP(0);
+        if (t + 1 < total) commit(t + 1, S0{});
+        RR_STAMP(1);
+        __syncthreads();
+        __syncthreads();
+        RR_STAMP(2);
+      }
+#ifdef MC_RR_STAMPS
+      if (blockIdx.x == 77 && blockIdx.y == 0 && threadIdx.x == 256)
+        printf("loader (dz) stages %d: epilogue + y loads %lld commit %lld barriers %lld issue %lld\n", total, st_acc[0], st_acc[1], st_acc[2], st_acc[3]);
+#endif
+      return;
+    } else {
     issue(0, S0{});
-    if (total > 1) issue(1, S1{});
+    if (total > 1) issue(1, std::integral_constant<int, NSET - 1>{});
     commit(0, S0{});
     __syncthreads();
     RR_STAMP(3);
-    // iteration t (the MFMA waves compute stage t): epilogue of stage t - 1 (FUSE == 2), loads of stage t + 2, delivery
-    // of stage t + 1.  FUSE == 2 has two barriers per stage: the accumulators are written to `exch` between them.
+    // iteration t (the MFMA waves compute stage t): loads of stage t + 2, delivery of stage t + 1
     for (int t = 0; t < total; t += 2) {
-      if (t > 0) epilogue_dz(t - 1);
-      load_y(t);
       if (t + 2 < total) issue(t + 2, S0{});                // set 0 held stage t (already in LDS)
       RR_STAMP(0);
       if (t + 1 < total) commit(t + 1, S1{});
       RR_STAMP(1);
       __syncthreads();
-      if (FUSE == 2) __syncthreads();
       RR_STAMP(2);
       if (t + 1 >= total) break;
-      epilogue_dz(t);
-      load_y(t + 1);
       if (t + 3 < total) issue(t + 3, S1{});
       RR_STAMP(0);
       if (t + 2 < total) commit(t + 2, S0{});
       RR_STAMP(1);
       __syncthreads();
-      if (FUSE == 2) __syncthreads();
       RR_STAMP(2);
     }
-    epilogue_dz(total - 1);
+    }
 #ifdef MC_RR_STAMPS
     if (blockIdx.x == 77 && blockIdx.y == 0 && threadIdx.x == 256)
       printf("loader stages %d: issue %lld commit %lld barrier %lld prologue %lld\n", total, st_acc[0], st_acc[1], st_acc[2], st_acc[3]);
@@ -399,6 +446,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #ifdef MC_RR_STAMPS
   long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = clock64();
 #endif
+
   for (int t = 0; t < total; ++t) {
     int n, ty0, tx0, ck, tile;
     stage_coords(t, n, ty0, tx0, ck, tile);
@@ -408,7 +456,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
     }
     // filter fragments of this chunk -> registers (loop invariants of the K loop; a single-chunk layer keeps them for
     // the whole kernel)
-    if (chunks == 1 && t > 0) {
+    // (DZM: re-read from LDS every stage -- 104 registers held across an epilogue that needs 32 more for y spill.  Moving
+    // these reads and the y loads behind the previous stage's epilogue, under the barrier, was tried: 85 spilled registers --
+    // the K loop then holds 104 + 64 + 32 + 16 live registers across the loop's back edge.)
+    if (!DZM && chunks == 1 && t > 0) {
     } else if (w_global) {
       const uint4* wsrc = reinterpret_cast<const uint4*>(bank) + ((size_t)(ck * ntiles_total + grp) * NFRAG) * 64 + lane;
 #pragma unroll
@@ -417,6 +468,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
       const uint4* ws = wbuf + ((NW == 2 && chunks > 1) ? (t & 1) : 0) * NFRAG * 64 + lane;
 #pragma unroll
       for (int f = 0; f < NFRAG; ++f) wf[f] = __builtin_bit_cast(bf16x8, ws[f * 64]);
+    }
+    // DZM: the producer's raw output y at this lane's pixels, in flight during the K loop.  Lanes of the even 16-lane rows
+    // load the 16-byte CB8 vector of output row r, the odd rows that of row r + 1 (r even); v_permlane16_swap hands every
+    // lane the four channels it holds accumulators for -- the store path of the epilogue run backwards.
+    // DZM: the producer's raw output y at this lane's pixels, in flight during the K loop.  Lanes of the even 16-lane rows
+    // load the 16-byte CB8 vector of output row r, the odd rows that of row r + 1 (r even); v_permlane16_swap hands every
+    // lane the four channels it holds accumulators for -- the store path of the epilogue run backwards.
+    v4u yl[DZM ? RR_R / 2 : 1];
+    if constexpr (DZM) {
+      const bf16_t* ey = reinterpret_cast<const bf16_t*>(fz.ey);
+      const int cx = min(max(tx0 + strip * 16 + m - fz.epad, 0), fz.ews - 1);
+#pragma unroll
+      for (int r = 0; r < RR_R; r += 2) {
+        const int cy = min(max(ty0 + r + (gq & 1) - fz.epad, 0), fz.ehs - 1);
+        yl[r / 2] = *reinterpret_cast<const v4u*>(ey + cb8_index(n, cbc, cy, cx, g.CBout, fz.ehs, fz.ews));
+      }
     }
     RR_STAMP(0);
     // ---- K loop: every input fragment of a row pair feeds up to K (+1) output rows.  Fragments are read three ahead
@@ -436,12 +503,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 #pragma unroll
       for (int kappa = S::kmin(T); kappa <= S::kmax(T); ++kappa) {
         const int r = i - kappa;
-        if (r >= 0 && r < RR_R) acc[r] = rr_mfma<(H16 && FUSE != 2)>(wf[S::fidx(T, kappa)], fr[k & 3], acc[r]);
+        if (r >= 0 && r < RR_R) acc[r] = rr_mfma<(H16 && FUSE != 2)>(wf[S::fidx(T, kappa)], fr[k & 3], acc[r]);   // (FUSE == 2: bf16 gradients)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     RR_STAMP(1);
-    if constexpr (FUSE == 2) {
+    if constexpr (LEX) {
       // hand the accumulators to the loader waves: exch [pixel][4 quads of 4 channels], quad index swizzled
       __syncthreads();                                      // every wave is done with the window (and the loaders with `exch`)
       if (ck == chunks - 1) {
@@ -453,10 +520,110 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
       }
     }
     RR_STAMP(4);
-    if (FUSE != 2 && ck == chunks - 1) {
+    if (!LEX && ck == chunks - 1) {
       // ---- epilogue: this lane holds, for pixel column ox and rows ty0 .. ty0 + 15, four consecutive output channels
       const int ox = tx0 + strip * 16 + m;
       f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}}, s2[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+      if constexpr (DZM) {
+        // ---- input gradient with the GroupNorm-backward reduction (MC_MIX16, GELU): dz = dA GELU'(scale y + shift) for the
+        // pixels whose value is final (raw dA for the frame that still awaits the padding adjoint), (sum dz, sum dz yhat)
+        // per channel.  The affine map, the polynomial GELU'(z) = 1/2 + z Q4(z^2) on |z| <= 3 (clamped: GELU'(3) = 1.012;
+        // evaluated in f16: rms error 1.6e-3 over z ~ N(0, 1), max 1.2e-2 in the tails -- the level of the bf16 rounding of
+        // dz itself) and g * y run on channel PAIRS (v_pk_*_f16); dA stays f32 and meets g through v_fma_mix_f32.  The
+        // second sum is taken as sum dz y and turned into sum dz yhat = rstd (sum dz y - mean sum dz) per lane.
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const int p = fz.epad, fr_ = fz.ezero ? 0 : p + 1;
+        const int ix = ox - p;
+        const bool colok = ox < g.Wo && cobok;
+        const bool colfin = colok && ix >= fr_ && ix < fz.ews - fr_;
+        float csc[4] = {1.f, 1.f, 1.f, 1.f}, csh[4] = {0.f, 0.f, 0.f, 0.f}, cme[4] = {0.f, 0.f, 0.f, 0.f}, crs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (fz.ecoef) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float4 c4 = reinterpret_cast<const float4*>(fz.ecoef)[(size_t)n * g.CoutP + cbc * 8 + (gq & 1) * 4 + r];
+            csc[r] = c4.x; csh[r] = c4.y; cme[r] = c4.z; crs[r] = c4.w;
+          }
+        }
+        const h2 sc01 = __builtin_bit_cast(h2, pk_f16(csc[0], csc[1])), sc23 = __builtin_bit_cast(h2, pk_f16(csc[2], csc[3]));
+        const h2 sh01 = __builtin_bit_cast(h2, pk_f16(csh[0], csh[1])), sh23 = __builtin_bit_cast(h2, pk_f16(csh[2], csh[3]));
+        float zero = 0.f;
+        asm volatile("" : "+v"(zero));                           // keeps dA * g a v_fma_mix_f32
+        float sd[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};     // sum dz, sum dz y of this lane's four channels
+        char* dst16 = reinterpret_cast<char*>(y0) + (cb8_index(n, cbc, ty0, ox, g.CBout, g.Ho, g.Wo)) * 2 + (size_t)(gq & 1) * g.Wo * 16;
+        const size_t row_bytes = (size_t)g.Wo * 16;
+        const int iy0 = ty0 - p;
+        auto rows = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;       // every pixel of the tile is inside and final: no masks
+#pragma unroll
+          for (int r = 0; r < RR_R; r += 2) {
+            const unsigned l0 = yl[r / 2][0], l1 = yl[r / 2][1], l2 = yl[r / 2][2], l3 = yl[r / 2][3];
+            const auto u01 = __builtin_amdgcn_permlane16_swap(l0, l2, false, false);      // [0]: row r, [1]: row r + 1
+            const auto u23 = __builtin_amdgcn_permlane16_swap(l1, l3, false, false);
+            // four chains in lock-step: (row r | r + 1) x (channels 01 | 23)
+            h2 yy[4] = {__builtin_bit_cast(h2, (unsigned)u01[0]), __builtin_bit_cast(h2, (unsigned)u23[0]),
+                        __builtin_bit_cast(h2, (unsigned)u01[1]), __builtin_bit_cast(h2, (unsigned)u23[1])};
+            h2 zc[4], w[4], q[4], gg[4];
+            const h2 R = {(_Float16)3.0f, (_Float16)3.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zc[c] = __builtin_elementwise_fma(yy[c], (c & 1) ? sc23 : sc01, (c & 1) ? sh23 : sh01);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zc[c] = __builtin_elementwise_max(zc[c], -R);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zc[c] = __builtin_elementwise_min(zc[c], R);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = zc[c] * zc[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              q[c] = __builtin_elementwise_fma((h2){(_Float16)1.3422040e-04f, (_Float16)1.3422040e-04f}, w[c],
+                                               (h2){(_Float16)-3.8080227e-03f, (_Float16)-3.8080227e-03f});
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = __builtin_elementwise_fma(q[c], w[c], (h2){(_Float16)4.2797559e-02f, (_Float16)4.2797559e-02f});
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = __builtin_elementwise_fma(q[c], w[c], (h2){(_Float16)-2.4320666e-01f, (_Float16)-2.4320666e-01f});
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = __builtin_elementwise_fma(q[c], w[c], (h2){(_Float16)7.8907706e-01f, (_Float16)7.8907706e-01f});
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gg[c] = __builtin_elementwise_fma(zc[c], q[c], (h2){(_Float16)0.5f, (_Float16)0.5f});
+            h2 gm[4], ge[4], hy[4];                              // multiplier of the sums / of the stored value; g y
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              gm[c] = gg[c]; ge[c] = gg[c];
+              if constexpr (!FULL) {
+                const int iy = iy0 + r + (c >> 1);
+                const bool fin = colfin && ty0 + r + (c >> 1) < g.Ho && iy >= fr_ && iy < fz.ehs - fr_;
+                gm[c] = fin ? gg[c] : (h2){(_Float16)0.f, (_Float16)0.f};
+                ge[c] = fin ? gg[c] : (h2){(_Float16)1.f, (_Float16)1.f};
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hy[c] = gm[c] * yy[c];
+            unsigned pk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float dA0 = acc[r + (c >> 1)][2 * (c & 1)], dA1 = acc[r + (c >> 1)][2 * (c & 1) + 1];
+              const float dz0 = __builtin_fmaf(dA0, (float)ge[c].x, zero), dz1 = __builtin_fmaf(dA1, (float)ge[c].y, zero);
+              sd[2 * (c & 1)] = __builtin_fmaf(dA0, (float)gm[c].x, sd[2 * (c & 1)]);
+              sd[2 * (c & 1) + 1] = __builtin_fmaf(dA1, (float)gm[c].y, sd[2 * (c & 1) + 1]);
+              sy[2 * (c & 1)] = __builtin_fmaf(dA0, (float)hy[c].x, sy[2 * (c & 1)]);
+              sy[2 * (c & 1) + 1] = __builtin_fmaf(dA1, (float)hy[c].y, sy[2 * (c & 1) + 1]);
+              pk[c] = pk_bf16(dz0, dz1);
+            }
+            const auto sx = __builtin_amdgcn_permlane16_swap(pk[0], pk[2], false, false);
+            const auto sz = __builtin_amdgcn_permlane16_swap(pk[1], pk[3], false, false);
+            if (FULL || (colok && ty0 + r + (gq & 1) < g.Ho))
+              *reinterpret_cast<uint4*>(dst16 + (size_t)r * row_bytes) = make_uint4(sx[0], sz[0], sx[1], sz[1]);
+          }
+        };
+        if (ty0 + RR_R <= g.Ho && tx0 + RR_TW <= g.Wo && grp * 2 + 1 < g.CBout && iy0 >= fr_ && iy0 + RR_R <= fz.ehs - fr_ &&
+            tx0 - p >= fr_ && tx0 - p + RR_TW <= fz.ews - fr_)
+          rows(std::true_type{});
+        else
+          rows(std::false_type{});
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sy[c] = crs[c] * (sy[c] - cme[c] * sd[c]);      // sum dz yhat
+        s1[0] = (f32x2){sd[0], sd[1]}; s1[1] = (f32x2){sd[2], sd[3]};
+        s2[0] = (f32x2){sy[0], sy[1]}; s2[1] = (f32x2){sy[2], sy[3]};
+      } else {
       constexpr int esz = OUT_F32 ? 4 : 2;
       char* dst;
       if (g.split8 > 0 && cbc >= g.split8)
@@ -544,8 +711,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         if (ty0 + RR_R <= g.Ho && tx0 + RR_TW <= g.Wo && grp * 2 + 1 < g.CBout) rows(std::true_type{});
         else rows(std::false_type{});
       }
+      }
       RR_STAMP(5);
-      float* pp = part;
+      float* pp = DZM ? fz.epart : part;
+      const int slots = DZM ? fz.estride : tiles4;
       if (pp) {
         // sum over the 16 pixel lanes of each 16-lane row with DPP row rotations (no LDS traffic: the ds_bpermute
         // butterfly cost 660 cycles per stage); every lane ends with the totals, lane m stores value index m >> 1
@@ -562,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         for (int k = 1; k < 8; ++k) q1 = (m >> 1) == k ? q8[k] : q1;
         const int co = grp * 16 + gq * 4 + (m >> 2);
         if ((m & 1) == 0 && co < g.CoutP) {
-          pp[(((size_t)n * tiles4 + (size_t)tile * RR_STRIPS + strip) * g.CoutP + co) * 2 + ((m >> 1) & 1)] = q1;
+          pp[(((size_t)n * slots + (size_t)tile * RR_STRIPS + strip) * g.CoutP + co) * 2 + ((m >> 1) & 1)] = q1;
         }
       }
     }
@@ -632,14 +801,15 @@ const char* mc_rr_kernel_name(const ConvGeom& g, int fuse) {
   return g.out_f32 ? "k_conv_rr_bf16<3,f32out>" : (fuse == 2 ? "k_conv_rr_bf16<3,dz>" : (fuse == 1 ? "k_conv_rr_bf16<3,norm>" : "k_conv_rr_bf16<3>"));
 }
 
-template <int K, int FUSE, bool F32, bool GELU, bool H16 = false>
+template <int K, int FUSE, bool F32, bool GELU, bool H16 = false, bool DZM = false>
 static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const void* bank, const float* bias, void* y0, void* y1,
                      float* part, const ConvFuse& fz, hipStream_t s) {
   using S = RR<K>;
-  const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (FUSE == 2 ? (size_t)RR_R * RR_TW * 64 : (size_t)2 * S::NFRAG * 1024);
+  constexpr bool LEX = FUSE == 2 && !DZM;                    // (the accumulator exchange area; see the kernel)
+  const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (LEX ? (size_t)RR_R * RR_TW * 64 : (size_t)2 * S::NFRAG * 1024);
   static bool attr_set = false;                              // one per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU, H16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU, H16, DZM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -649,7 +819,7 @@ static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const vo
   static const int cap_total = [] { const char* e = getenv("MC_RR_CAP"); return e ? atoi(e) : 256; }();   // one work-group per CU
   int cap = cap_total / groups > 0 ? cap_total / groups : 1;
   const int bx = items < cap ? items : cap;
-  hipLaunchKernelGGL((k_conv_rr_bf16<K, FUSE, F32, GELU, H16>), dim3(bx, groups, 1), dim3(512), lds, s, g, (const bf16_t*)x0,
+  hipLaunchKernelGGL((k_conv_rr_bf16<K, FUSE, F32, GELU, H16, DZM>), dim3(bx, groups, 1), dim3(512), lds, s, g, (const bf16_t*)x0,
                      (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part, fz);
   MC_CHECK_LAUNCH();
   return MC_OK;
@@ -674,6 +844,11 @@ int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* 
     if (g.out_f32) return gelu ? RRL(K, 1, true, true, H) : RRL(K, 1, true, false, H);                          \
     return gelu ? RRL(K, 1, false, true, H) : RRL(K, 1, false, false, H);                                       \
   } while (0)
+  // MC_MIX16 + GELU + at most 16 input channels of the launch: the MFMA-side packed-f16 epilogue
+  if (h16 && fuse == 2 && gelu && g.CBin <= 2) {
+    if (g.K == 5) return rr_launch<5, 2, false, true, true, true>(g, x0, x1, bank, bias, y0, y1, part, fz, s);
+    return rr_launch<3, 2, false, true, true, true>(g, x0, x1, bank, bias, y0, y1, part, fz, s);
+  }
   if (h16) { if (g.K == 5) RRK(5, true); RRK(3, true); }
   if (g.K == 5) RRK(5, false);
   RRK(3, false);

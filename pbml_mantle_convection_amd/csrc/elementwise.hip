@@ -652,6 +652,35 @@ __global__ __launch_bounds__(1024) void k_gn_bwd_finalize(const float* __restric
   }
 }
 
+// phase 2 for partial tables with MANY slots per sample (the input-gradient epilogue writes one per (tile, strip): 1100+ at
+// 506 x 512): one block per (group, sample) -- N x groups blocks instead of `groups` (the one-block form above walks the
+// samples with 16 waves: 62 us for a level-0 layer, latency-bound) -- writes m12[n][g] and the per-(sample, channel) sums
+// pc[n][CP][2] = (sum dz, sum dz yhat); dgamma / dbeta are accumulated from pc in sample order by k_gn_param_grads.
+// The four waves take a quarter of the slots each and are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_gn_bwd_finalize_n(const float* __restrict__ part, int blocks, int C, int CP, int groups, int hw,
+                                                           const float* __restrict__ gamma, float* __restrict__ m12,
+                                                           float* __restrict__ pc) {
+  const int g = blockIdx.x, n = blockIdx.y, cpg = C / groups;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double sm[4][16];
+  const int per = (blocks + 3) / 4, b0 = wave * per, cnt = max(0, min(per, blocks - b0));
+  double a1, a2;
+  group_channel_sums(part, (size_t)n * blocks + b0, cnt, CP, g * cpg, cpg, a1, a2);      // cpg is a power of two <= 8 (host check)
+  if (lane < cpg) { sm[wave][2 * lane] = a1; sm[wave][2 * lane + 1] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2 * cpg) {
+    const double t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    pc[((size_t)n * CP + g * cpg + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)] = (float)t;
+    sm[0][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && m12) {
+    double m = 0.0;
+    for (int k = 0; k < cpg; ++k) m += (double)(gamma ? gamma[g * cpg + k] : 1.f) * sm[0][2 * k + threadIdx.x];
+    m12[((size_t)n * groups + g) * 2 + threadIdx.x] = (float)(m / ((double)cpg * (double)hw));
+  }
+}
+
 // phase 3: dy = rstd (dz gamma - m1 - yhat m2)   (GN)   |   dy = da act'(y)   (act only)
 template <typename T, int GK = 0, typename TY = T>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnArgs a, const TY* __restrict__ y, const float* __restrict__ m12,
@@ -1703,6 +1732,17 @@ int mc_gn_act_bwd_finalize(const float* partials, int32_t n, int32_t blocks, int
   if (!partials || n <= 0 || blocks <= 0 || c <= 0 || groups <= 0 || c % groups || hw <= 0) return MC_EINVAL;
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(groups), dim3(1024), 0, (hipStream_t)stream, partials, n, blocks, c,
                      ((c + 7) / 8) * 8, groups, hw, gamma, m12, dgamma, dbeta);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_gn_act_bwd_finalize_n(const float* partials, int32_t n, int32_t blocks, int32_t c, int32_t groups, int32_t hw,
+                             const float* gamma, float* m12, float* chan_sums, void* stream) {
+  if (!partials || !chan_sums || n <= 0 || blocks <= 0 || c <= 0 || groups <= 0 || c % groups || hw <= 0) return MC_EINVAL;
+  const int cpg = c / groups;
+  if (cpg != 1 && cpg != 2 && cpg != 4 && cpg != 8) return MC_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_gn_bwd_finalize_n, dim3(groups, n), dim3(256), 0, (hipStream_t)stream, partials, blocks, c,
+                     ((c + 7) / 8) * 8, groups, hw, gamma, m12, chan_sums);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

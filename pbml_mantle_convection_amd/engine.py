@@ -384,6 +384,11 @@ class Engine:
         # costs more than the streaming pass it replaces (level-0 16->16 forward 117 -> 207 us against a 100 us pass);
         # at the deep levels the kernels are launch-latency bound and every fused pass is a launch saved.
         self.fuse_maxpix = int(os.environ.get("MANTLE_FUSE_MAXPIX", str(128 * 128)))
+        # "mixed" mode, round 3: the GroupNorm-backward reduction rides in the input-gradient launch of every eligible layer
+        # whose launch is a row-reuse launch (the wide levels).  y is f16 there, so dz = dA * GELU'(z) and the two sums cost
+        # 8.5 packed-f16 / mixed-precision instructions per element on the loader waves, beside the next stage's MFMAs,
+        # instead of the ~25 f32 instructions that made the same fusion lose in round 2.
+        self.fuse_dz_rr = precision == "mixed" and os.environ.get("MANTLE_FUSE_DZ_RR", "1") != "0"
         # precision "mixed": every full-resolution tensor of the FORWARD pass (packed input, conv outputs, activations) is
         # carried to ~16 mantissa bits -- conv outputs in f32, activations as (hi, lo) bf16 pairs that the next conv reads as
         # two sources with its filters repeated (2 x the MFMA work of those layers; the backward pass is plain bf16).  The
@@ -583,9 +588,13 @@ class Engine:
                 # GroupNorm-backward reduction fused into this launch's epilogue: the source is the full-resolution output
                 # of a conv + (GN) + act layer and this conv is its only consumer
                 pe = self.prod.get(node.srcs[0])
-                if ((self.fuse & 2) and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
+                dz_here = bool(self.fuse & 2) and h * w <= self.fuse_maxpix
+                if (not dz_here and self.fuse_dz_rr and g.act == "gelu"
+                        and L.load().mc_conv_kernel_name(C.byref(dd)).decode().startswith("k_conv_rr")):
+                    dz_here = True
+                if (dz_here and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
                         and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1
-                        and h * w <= self.fuse_maxpix and not hp_in and not pe.get("split")):
+                        and not hp_in and not pe.get("split")):
                     dtiles = L.call("mc_conv_tiles", C.byref(dd))
                     fblocks = L.call("mc_fold_blocks", h, w, node.pad, mode)
                     e["epi"] = pe
@@ -593,6 +602,9 @@ class Engine:
                     pe["dz_part"] = torch.empty((N, dtiles + fblocks, pe["coutp"], 2), **f32)
                     if "m12" not in pe and pe["node"].post == L.POST_GN_ACT:
                         pe["m12"] = torch.empty((N, pe["node"].groups, 2), **f32)
+                    if (pe["node"].post == L.POST_GN_ACT and pe["dz_blocks"] > 256
+                            and (pe["node"].c_out // pe["node"].groups) in (1, 2, 4, 8)):
+                        pe["dz_pc"] = torch.empty((N, pe["coutp"], 2), **f32)
             max_dy = max(max_dy, N * coutp * ho * wo)
             # per-layer filter-gradient partial slabs: all layers are combined by ONE batched launch at the end of backward
             e["wpart"] = torch.empty(L.call("mc_wgrad_partial_bytes", C.byref(d)), dtype=torch.uint8, device=device)
@@ -819,7 +831,7 @@ class Engine:
                            L.ptr(e["part"]) if need_part else None, None, st)
                 self._probe_end(d, "fwd " + node.name)
             small = (node.post == L.POST_GN_ACT and "pc" in e and not o.fused and not e.get("split") and node.pool in (1, 2)
-                     and not node.learned and self.fuse == 0)
+                     and not node.learned and (self.fuse == 0 or self.fuse_dz_rr) and "dz_blocks" not in e)
             if small:
                 # statistics + activation (+ pooling) of a small layer in one launch
                 pooled = T[node.pooled].buf if node.pool > 1 else None
@@ -972,9 +984,16 @@ class Engine:
                 assert not o.gsrcs, f"{node.name}: fused dz and separate gradient sources"
                 if node.post == L.POST_GN_ACT:
                     gamma = self._param(params, node.gn_name + "weight")
-                    L.call("mc_gn_act_bwd_finalize", L.ptr(e["dz_part"]), N, e["dz_blocks"], node.c_out, node.groups,
-                           o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
-                           L.ptr(grads[node.gn_name + "bias"]), st)
+                    if "dz_pc" in e:
+                        # many slots per sample: one block per (group, sample); dgamma / dbeta join the batched launch below
+                        L.call("mc_gn_act_bwd_finalize_n", L.ptr(e["dz_part"]), N, e["dz_blocks"], node.c_out, node.groups,
+                               o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(e["dz_pc"]), st)
+                        gp_jobs.append((L.ptr(e["dz_pc"]), node.c_out, L.ptr(grads[node.gn_name + "weight"]),
+                                        L.ptr(grads[node.gn_name + "bias"])))
+                    else:
+                        L.call("mc_gn_act_bwd_finalize", L.ptr(e["dz_part"]), N, e["dz_blocks"], node.c_out, node.groups,
+                               o.H * o.W, L.ptr(gamma), L.ptr(e["m12"]), L.ptr(grads[node.gn_name + "weight"]),
+                               L.ptr(grads[node.gn_name + "bias"]), st)
                 L.call("mc_gn_bwd_apply_dz", C.byref(e["dz"]), L.ptr(e["Y"]), N, node.c_out, o.H, o.W, max(node.groups, 1),
                        L.ptr(e["coef"]) if node.post == L.POST_GN_ACT else None, L.ptr(e.get("m12")), self.mc_dtype,
                        L.ptr(dY), st)

@@ -12,9 +12,11 @@ executions can be compared directly:
     execution's as the unfused one is (error norm <= 2 x the unfused error + 1 % of the gradient norm; the fused path
     rounds dz = dA act'(z) once where the unfused path rounds dA and then dy: a different, not a larger, rounding).
 Both executions are separately pinned against the reference's golden vectors by the other GPU test files (the default
-execution there is the fused one); reference call sites: FluidLayer.forward pytorch_networks_convae.py:790-799,
+execution there is the unfused one, MANTLE_FUSE=0, except for the "mixed" mode's dz epilogue); reference call sites: FluidLayer.forward pytorch_networks_convae.py:790-799,
 Unet.forward :1985-2024, ConvAE.forward pycold-checkpoint.py:1094-1115."""
 import ctypes as C
+
+import os
 
 import numpy as np
 import pytest
@@ -36,6 +38,8 @@ def _build(kind, r_p, seed):
         return Unet(3, 10, 8, 4, torch.device(DEV), "gelu", r_p, "mae", use_symm=True, repeats=2, f=5, p_pred=True), (2, 10, 44, 70)
     if kind == "unet16":
         return Unet(3, 10, 16, 4, torch.device(DEV), "gelu", r_p, "mae", use_symm=True, repeats=3, f=5, p_pred=True), (2, 10, 70, 90)
+    if kind == "unet16w":      # wide enough (150 + 6 + 4 >= 140 columns) for the row-reuse kernel's input-gradient launches
+        return Unet(2, 10, 16, 4, torch.device(DEV), "gelu", r_p, "mae", use_symm=True, repeats=3, f=5, p_pred=True), (2, 10, 40, 150)
     return ConvAE(2, 3, 16, 3, torch.device(DEV), "gelu", r_p, "mae", use_symm=True, repeats=2, f=3, p_pred=True), (2, 3, 64, 48)
 
 
@@ -64,9 +68,10 @@ def _run(monkeypatch, fuse, kind, r_p, precision, seed=3):
 
 
 @pytest.mark.parametrize("kind,r_p", [("unet", "reflect"), ("unet", "zeros"), ("unet16", "replicate"), ("unet16", "reflect"),
-                                      ("convae", "reflect"), ("convae", "zeros")])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+                                      ("convae", "reflect"), ("convae", "zeros"), ("unet16w", "reflect"), ("unet16w", "zeros")])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed"])
 def test_fused_network_matches_unfused(monkeypatch, kind, r_p, precision):
+    monkeypatch.setenv("MANTLE_FUSE_DZ_RR", "0")                 # (the unfused reference run must be unfused in "mixed" too)
     y0, g0, m0 = _run(monkeypatch, 0, kind, r_p, precision)
     y3, g3, m3 = _run(monkeypatch, 3, kind, r_p, precision)
     fused = [t for t in m3.engine().T.values() if t.fused]
@@ -84,7 +89,7 @@ def test_fused_network_matches_unfused(monkeypatch, kind, r_p, precision):
             e0, ek = float((g0[n] - gref[n]).norm()), float((gk[n] - gref[n]).norm())
             assert ek <= 2.0 * e0 + 1e-2 * float(gref[n].norm()), (what, n, ek, e0, float(gref[n].norm()))
 
-    if precision == "bf16":
+    if precision != "fp32":
         _, gref, _ = _run(monkeypatch, 0, kind, r_p, "fp32")
         assert torch.equal(y0, y3), float((y0 - y3).abs().max())
     else:
@@ -93,9 +98,16 @@ def test_fused_network_matches_unfused(monkeypatch, kind, r_p, precision):
     # forward-only fusion (bit 0) and epilogue-only fusion (bit 1) are valid executions on their own
     for fuse in (1, 2):
         yk, gk, _ = _run(monkeypatch, fuse, kind, r_p, precision)
-        if precision == "bf16":
+        if precision != "fp32":
             assert torch.equal(y0, yk)
         check(gk, fuse)
+    if precision == "mixed":
+        # the "mixed" mode's default: the dz epilogue (packed-f16 GELU') on the row-reuse input-gradient launches only
+        monkeypatch.setenv("MANTLE_FUSE_DZ_RR", "1")
+        yk, gk, mk = _run(monkeypatch, 0, kind, r_p, precision)
+        assert torch.equal(y0, yk)
+        assert any("epi" in e for e in mk.engine().plan) == (kind == "unet16w")
+        check(gk, "dz_rr")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -189,10 +201,13 @@ def test_conv_prologue_and_filter_gradient_prologue(dt, mode, ci0, ci1, co, k, h
         assert rel_l2(dws[1][0], dws[0][0]) <= 1e-6 and rel_l2(dws[1][1], dws[0][1]) <= 1e-6
 
 
-@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+@pytest.mark.parametrize("dt", ["bf16", "fp32", "mixed"])
 @pytest.mark.parametrize("mode,c,co,k,hw,gn", [("reflect", 16, 16, 5, (37, 45), True), ("zeros", 16, 32, 5, (21, 33), True),
                                                ("replicate", 32, 16, 3, (18, 20), True), ("reflect", 64, 64, 5, (17, 19), False),
-                                               ("reflect", 16, 16, 5, (4, 5), True)])
+                                               ("reflect", 16, 16, 5, (4, 5), True),
+                                               # >= 140 columns on the padded domain: the row-reuse kernel's epilogue (loader waves)
+                                               ("reflect", 16, 16, 5, (37, 150), True), ("zeros", 16, 16, 5, (20, 140), True),
+                                               ("replicate", 16, 32, 5, (33, 141), False), ("reflect", 32, 16, 3, (18, 200), True)])
 def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
     """Input-gradient launch with the GroupNorm-backward epilogue + mc_fold_padded_dz, against an fp64 evaluation from the
     same stored operands: dz = fold(conv^T(dY)) * act'(scale y + shift) on the interior of the padded buffer, and
@@ -201,10 +216,12 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
     import torch.nn.functional as F
     from pbml_mantle_convection_amd import _lib as L
     lib = L.load()
-    mcd, tdt = (L.MC_BF16, torch.bfloat16) if dt == "bf16" else (L.MC_F32, torch.float32)
+    # "mixed": the layer is MC_MIX16 (y is f16), its input-gradient launch and every gradient tensor are bf16
+    mcd, tdt = (L.MC_F32, torch.float32) if dt == "fp32" else (L.MC_BF16, torch.bfloat16)
+    mcl, ydt = (L.MC_MIX16, torch.float16) if dt == "mixed" else (mcd, tdt)
     N, (H, W), p = 2, hw, k // 2
     g = torch.Generator().manual_seed(c * 100 + co + k)
-    y = _cb8(torch.randn((N, c, H, W), generator=g) * 1.2 + 0.2, tdt)
+    y = _cb8(torch.randn((N, c, H, W), generator=g) * 1.2 + 0.2, ydt)
     dY = _cb8(torch.randn((N, co, H, W), generator=g), tdt)
     wt = (torch.randn((co, c, k, k), generator=g) / (c * k * k) ** 0.5).to(DEV)
     groups = c // 4
@@ -216,7 +233,7 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
         mean_c, rstd_c = mean.repeat_interleave(4, 1), rstd.repeat_interleave(4, 1)
         coef = torch.stack([rstd_c * gamma, beta - mean_c * rstd_c * gamma, mean_c, rstd_c], -1).float().to(DEV).contiguous()
     st = torch.cuda.current_stream().cuda_stream
-    d = L.ConvDesc(N, H, W, c, 0, co, k, p, L.PAD_MODES[mode], mcd, 0, 0, 0)
+    d = L.ConvDesc(N, H, W, c, 0, co, k, p, L.PAD_MODES[mode], mcl, 0, 0, 0)
     dd = L.ConvDesc(N, H, W, co, 0, c, k, k - 1, 0, mcd, 0, 0, 0)
     dbank = torch.empty(lib.mc_packed_weight_bytes(C.byref(d), 1), dtype=torch.uint8, device=DEV)
     L.call("mc_pack_weights", C.byref(d), wt.data_ptr(), 1, dbank.data_ptr(), st)
@@ -224,10 +241,11 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
     fb = lib.mc_fold_blocks(H, W, p, L.PAD_MODES[mode])
     part = torch.full((N, tiles + fb, c, 2), float("nan"), device=DEV)
     dxp = torch.zeros((N, c // 8, H + 2 * p, W + 2 * p, 8), dtype=tdt, device=DEV)
-    epi = L.ConvEpilogue(y.data_ptr(), L.ptr(coef), L.ACTS["gelu"], p, L.PAD_MODES[mode], H, W, part.data_ptr(), tiles + fb)
+    epi = L.ConvEpilogue(y.data_ptr(), L.ptr(coef), L.ACTS["gelu"], p, L.PAD_MODES[mode], H, W, part.data_ptr(), tiles + fb,
+                         int(dt == "mixed"))
     L.call("mc_conv2d_fused", C.byref(dd), dY.data_ptr(), None, None, dbank.data_ptr(), None, dxp.data_ptr(), None, None,
            C.byref(epi), st)
-    L.call("mc_fold_padded_dz", dxp.data_ptr(), N, c, H, W, p, L.PAD_MODES[mode], mcd, y.data_ptr(), L.ptr(coef), L.ACTS["gelu"],
+    L.call("mc_fold_padded_dz", dxp.data_ptr(), N, c, H, W, p, L.PAD_MODES[mode], mcl, y.data_ptr(), L.ptr(coef), L.ACTS["gelu"],
            part.data_ptr(), tiles + fb, tiles, st)
     torch.cuda.synchronize()
     # fp64 reference from the stored (rounded) operands and the bank's rounded weights
@@ -246,21 +264,34 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
     (gp,) = torch.autograd.grad(F.gelu(z).sum(), z)
     dz = dA * gp
     got = _from_cb8(dxp, c).double()[:, :, p:p + H, p:p + W]
-    tol = 1e-2 if dt == "bf16" else 2e-5
+    # ("mixed" on the row-reuse kernel: GELU' is the packed-f16 polynomial, max error 1.2e-2 in the tails, rms 1.6e-3)
+    tol = {"bf16": 1e-2, "fp32": 2e-5, "mixed": 2.5e-2}[dt]
+    stol = {"bf16": 2e-3, "fp32": 1e-5, "mixed": 4e-3}[dt]
+    print(f"\n{dt} {mode} {c}->{co} k{k} {hw}: max |dz err| / max |dz| = {float((got - dz).abs().max()) / float(dz.abs().max()):.3e}, "
+          f"rms {float((got - dz).pow(2).mean().sqrt()) / float(dz.pow(2).mean().sqrt()):.3e}")
+    if os.environ.get("DBG_DZ"):
+        e = (got - dz)
+        print("per-channel rms err / rms dz:", [round(float(e[:, ch].pow(2).mean().sqrt() / dz[:, ch].pow(2).mean().sqrt()), 3) for ch in range(c)])
+        print("err vs dA:", float((got - dA).abs().max()), " err vs 0.5 dA:", float((got - 0.5 * dA).abs().max()), " |dz|max", float(dz.abs().max()))
+        gg = got / dA
+        print("implied g sample (got/dA) vs true g:", gg[0, 0, 10, 60:68].tolist(), gp[0, 0, 10, 60:68].tolist())
+        print("implied g ch1:", gg[0, 1, 10, 60:68].tolist(), gp[0, 1, 10, 60:68].tolist())
+        print("z sample:", z[0, 0, 10, 60:68].tolist())
     assert float((got - dz).abs().max()) <= tol * float(dz.abs().max()), float((got - dz).abs().max())
     s = part.double().cpu().sum(1)                 # [N, c, 2]
     assert torch.isfinite(s).all()
     ref1, ref2 = dz.sum((2, 3)), (dz * (y64 - me) * rs).sum((2, 3))
     scale = float(dz.abs().sum((2, 3)).max())
-    assert float((s[..., 0] - ref1).abs().max()) <= (2e-3 if dt == "bf16" else 1e-5) * scale
+    print(f"   sums: S1 err / sum|dz| {float((s[..., 0] - ref1).abs().max()) / scale:.3e}")
+    assert float((s[..., 0] - ref1).abs().max()) <= stol * scale
     if gn:
-        assert float((s[..., 1] - ref2).abs().max()) <= (2e-3 if dt == "bf16" else 1e-5) * float((dz * (y64 - me) * rs).abs().sum((2, 3)).max())
+        assert float((s[..., 1] - ref2).abs().max()) <= stol * float((dz * (y64 - me) * rs).abs().sum((2, 3)).max())
     # last phase from dz: dy = scale dz - rstd (m1 + yhat m2)
     m12 = torch.stack([0.01 * torch.randn((N, groups), generator=g), 0.02 * torch.randn((N, groups), generator=g)], -1).to(DEV)
     dy = torch.zeros((N, c // 8, H, W, 8), dtype=tdt, device=DEV)
     gs = L.GradSrc(dxp.data_ptr(), L.GSRC_PADFOLD, p, L.PAD_MODES[mode], 1, H, W, 0, 0)
     L.call("mc_gn_bwd_apply_dz", C.byref(gs), y.data_ptr(), N, c, H, W, groups, L.ptr(coef), m12.data_ptr() if gn else None,
-           mcd, dy.data_ptr(), st)
+           mcl, dy.data_ptr(), st)
     torch.cuda.synchronize()
     if gn:
         m1 = m12[..., 0].double().cpu().repeat_interleave(4, 1).view(N, c, 1, 1)
@@ -269,7 +300,7 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
     else:
         ref = got
     err = float((_from_cb8(dy, c).double() - ref).abs().max())
-    assert err <= (1e-2 if dt == "bf16" else 2e-5) * float(ref.abs().max()), err
+    assert err <= (2e-5 if dt == "fp32" else 1e-2) * float(ref.abs().max()), err
 
 
 @pytest.mark.parametrize("hw", [(37, 70), (20, 140)])

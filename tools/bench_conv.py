@@ -15,19 +15,22 @@ p.add_argument("--which", default="fwd,dgrad,wgrad"); p.add_argument("--sym", ty
 a = p.parse_args()
 L.load()
 dev = "cuda:0"
-mc = L.MC_BF16 if a.dtype == "bf16" else L.MC_F32
-tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-es = 2 if a.dtype == "bf16" else 4
+# "mixed": MC_MIX16 layer (f16 forward tensors, bf16 gradient tensors and input-gradient launch)
+mc = {"bf16": L.MC_BF16, "mixed": L.MC_MIX16}.get(a.dtype, L.MC_F32)
+mcg = L.MC_BF16 if a.dtype == "mixed" else mc
+tdt = {"bf16": torch.bfloat16, "mixed": torch.float16}.get(a.dtype, torch.float32)
+gdt = torch.bfloat16 if a.dtype == "mixed" else tdt
+es = 4 if a.dtype == "fp32" else 2
 N, (H, W) = a.n, a.hw
 pad = a.k // 2
 cin = a.cin + a.cin1
 d = L.ConvDesc(N, H, W, a.cin, a.cin1, a.cout, a.k, pad, 2, mc, a.sym, 0, 0)
-dd = L.ConvDesc(N, H, W, a.cout, 0, cin, a.k, a.k - 1, 0, mc, 0, a.cin if a.cin1 else 0, 0)
+dd = L.ConvDesc(N, H, W, a.cout, 0, cin, a.k, a.k - 1, 0, mcg, 0, a.cin if a.cin1 else 0, 0)
 st = L.stream()
-cb = lambda c, h, w: torch.randn((N, (c + 7) // 8, h, w, 8), device=dev).to(tdt)
+cb = lambda c, h, w, t=tdt: torch.randn((N, (c + 7) // 8, h, w, 8), device=dev).to(t)
 x0 = cb(a.cin, H, W); x1 = cb(a.cin1, H, W) if a.cin1 else None
-y = cb(a.cout, H, W); dy = cb(a.cout, H, W)
-dx0 = cb(a.cin, H + 2 * pad, W + 2 * pad); dx1 = cb(a.cin1, H + 2 * pad, W + 2 * pad) if a.cin1 else None
+y = cb(a.cout, H, W); dy = cb(a.cout, H, W, gdt)
+dx0 = cb(a.cin, H + 2 * pad, W + 2 * pad, gdt); dx1 = cb(a.cin1, H + 2 * pad, W + 2 * pad, gdt) if a.cin1 else None
 U = a.cout - a.sym // 2
 w = torch.randn((U, cin, a.k, a.k), device=dev) / (cin * a.k * a.k) ** 0.5
 b = torch.zeros(a.cout, device=dev)
@@ -48,7 +51,7 @@ dtiles = L.call("mc_conv_tiles", C.byref(dd))
 fb = L.call("mc_fold_blocks", H, W, pad, 2)
 epart = torch.empty((N, dtiles + fb, cp8(cin), 2), device=dev)
 ecoef = torch.randn((N, cp8(cin), 4), device=dev) * 0.1 + torch.tensor([1.0, 0.0, 0.0, 1.0], device=dev)
-epi = L.ConvEpilogue(L.ptr(x0), L.ptr(ecoef), L.ACTS["gelu"], pad, 2, H, W, L.ptr(epart), dtiles + fb)
+epi = L.ConvEpilogue(L.ptr(x0), L.ptr(ecoef), L.ACTS["gelu"], pad, 2, H, W, L.ptr(epart), dtiles + fb, int(a.dtype == "mixed"))
 ops = {
     "fwdn": (lambda: L.call("mc_conv2d_fused", C.byref(d), L.ptr(x0), L.ptr(x1), C.byref(pro), L.ptr(bank), L.ptr(b), L.ptr(y), None, L.ptr(part), None, st),
              N * es * (cin + a.cout) * H * W),
