@@ -70,21 +70,22 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MANTLE_CPU_THREADS", "16"))))
 
 
-PMC_FILE = "round2_pmc_traffic.json"
+PMC_FILE = "round3_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, B, H, W, precision):
     """(HBM bytes per launch of the dominant kernel, commit they were measured at) from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 + WRITE_SIZE, profiles/round2_pmc_traffic.json, collected on this same workload by tools/profile_round.sh);
+    (FETCH_SIZE x2 + WRITE_SIZE, profiles/round3_pmc_traffic.json, collected on this same workload by tools/profile_round.sh);
     (None, None) for any other workload.  The counters cannot be read inside this process: the figure is as old as its commit."""
     if (B, H, W) != (32, 506, 506) or precision not in ("bf16", "mixed", "split"):
         return None, None
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
-        # the probe names the kernel family (k_conv_rr_bf16<5>); the counters are per instantiation: launch-weighted mean
+        # the probe names the kernel family (k_conv_rr_bf16<5>: every instantiation for that filter size); the counters are
+        # per instantiation: launch-weighted mean over the same family
         fam = kernel.replace(" ", "").rstrip(">")
-        ks = [v for n, v in d["kernels"].items() if n == kernel.replace(" ", "") or n.startswith(fam + ",")]
+        ks = [v for n, v in d["kernels"].items() if n == fam + ">" or n.startswith(fam + ",")]
         if not ks:
             return None, None
         return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks), d.get("commit")

@@ -807,7 +807,12 @@ static int rr_launch(const ConvGeom& g, const void* x0, const void* x1, const vo
   using S = RR<K>;
   constexpr bool LEX = FUSE == 2 && !DZM;                    // (the accumulator exchange area; see the kernel)
   const size_t lds = (size_t)2 * 2 * S::PLANE * 16 + (LEX ? (size_t)RR_R * RR_TW * 64 : (size_t)2 * S::NFRAG * 1024);
-  static bool attr_set = false;                              // one per instantiation
+  // (the attribute belongs to the CURRENT DEVICE's function object: one flag per instantiation and device, so that a process
+  // driving several GPUs opts every one of them in)
+  static bool attr_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MC_EINVAL;
+  bool& attr_set = attr_dev[dev];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rr_bf16<K, FUSE, F32, GELU, H16, DZM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

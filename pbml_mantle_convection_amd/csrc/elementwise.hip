@@ -1276,6 +1276,10 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
   V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
 }
 
+// (Round 3 tried a streaming form -- wave = input row, lanes over the output columns, the row's transposed tap list summed
+// straight from global memory, then an x pass from one f32 row in LDS: +0.12 ms per step.  Every output row is read by the
+// four input rows it feeds, and those re-reads come from L2, not from the 16 KB L1: 4 x the bytes cross the L2 -> CU path.
+// The LDS window above is the right structure; what it costs is reading the window 8 + 8 times through LDS.)
 // adjoint of the bicubic upsample for LARGE scale factors (NewFluidNet: x4, x8, x16), where the tile window of the kernel
 // above does not fit and its per-pixel fallback gathers taps_y x taps_x (up to 64 x 64) vectors: two 1-D passes through an
 // f32 intermediate [n][c8][hi][wo][8] instead (taps_y + taps_x per pixel, coalesced along x).
@@ -2006,9 +2010,9 @@ int mc_bicubic_bwd_taps(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi,
   if (gs->hs != ho || gs->ws != wo) return MC_EINVAL;
   if (gs->kind != MC_GSRC_PLAIN && gs->kind != MC_GSRC_PADFOLD) return MC_EUNSUPPORTED;   // the window is staged raw
   int C8 = (c + 7) / 8;
+  hipStream_t s = (hipStream_t)stream;
   int tiles_x = cdiv(wi, BT), tiles_y = cdiv(hi, BT);
   dim3 g(tiles_x * tiles_y, C8, n);
-  hipStream_t s = (hipStream_t)stream;
   const bool y8 = max_taps_y > 0 && max_taps_y <= 8, x8 = max_taps_x > 0 && max_taps_x <= 8;
 #define BW(T, A, B) hipLaunchKernelGGL((k_bicubic_bwd<T, A, B>), g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (T*)dx, tiles_x)
 #define BWT(T) do { if (y8 && x8) BW(T, 8, 8); else if (y8) BW(T, 8, 12); else if (x8) BW(T, 12, 8); else BW(T, 12, 12); } while (0)

@@ -1158,8 +1158,16 @@ class Engine:
             self._probe.append((name, shape, self._probe_ev, ev, nbytes, flops))
 
     @staticmethod
+    def kernel_family(name):
+        """k_conv_rr_bf16<5,f32out> -> k_conv_rr_bf16<5>: every instantiation of a kernel for one filter size is ONE family
+        (forward f16 / input gradient bf16 / dz epilogue / f32 output differ in a few instructions of the same schedule)."""
+        return name.split(",")[0].rstrip(">") + ">"
+
+    @staticmethod
     def probe_summary(probe, hbm_peak_gbs):
-        """Dominant conv kernel (largest total time): algorithmic bytes per launch / mean launch duration."""
+        """Dominant conv kernel FAMILY (largest total time): algorithmic bytes per launch / mean launch duration over ALL its
+        launches of a step -- the same set of launches bench.py's `traffic` figure is weighted over."""
+        probe = [(Engine.kernel_family(name), *rest) for name, *rest in probe]
         groups = {}
         for name, label, e0, e1, nbytes, flops in probe:
             g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, flops=0.0, n=0))

@@ -236,6 +236,38 @@ def test_graph_step_in_place_input_buffers():
     assert torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_second_batch_on_a_different_mesh_raises(use_graph):
+    """The momentum residual uses ONE depth grid for the whole batch: a LATER batch (not only the first) whose samples carry
+    different grids must raise -- also in the captured step, where the check runs on the caller's tensor before the staging
+    copy, and also when the caching allocator hands the second batch the first one's address."""
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    torch.manual_seed(3)
+    m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet",
+                 loss_type="mass", lambda_mom=0.1, precision="fp32", use_graph=use_graph)
+    gVTp, uvp, scaler, paras, yc = [t.to(DEV) for t in synthetic_batch(2, 48, 70, 11, p_pred=True, device="cpu")]
+    yc = yc.reshape(-1, 48, 70)[:1].repeat(2, 1, 1).contiguous()          # one grid per sample, as a DataLoader collates them
+    tr.train_step(gVTp, uvp, yc, paras, scaler)
+    yc_bad = yc.clone()
+    ptr = yc_bad.data_ptr()
+    yc_bad[1] += 0.01
+    with pytest.raises(ValueError, match="one depth grid"):
+        tr.train_step(gVTp, uvp, yc_bad, paras, scaler)
+    del yc_bad
+    yc_ok = yc.clone()                                        # (usually the freed block again)
+    tr.train_step(gVTp, uvp, yc_ok, paras, scaler)
+    yc_bad2 = yc.clone()
+    yc_bad2[0, 3] -= 0.5
+    with pytest.raises(ValueError, match="one depth grid"):
+        tr.train_step(gVTp, uvp, yc_bad2, paras, scaler)
+    assert ptr                                                # (keeps the address in the failure report)
+
+
 # ---------------------------------------------------------------------------------------------- SURVEY 8(f) N1: NewFluidNet
 @pytest.mark.parametrize("p_pred", [True, False])
 @pytest.mark.parametrize("loss_type", ["mae", "mass", "curl"])
