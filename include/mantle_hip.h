@@ -180,6 +180,10 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
  * reduces it deterministically, folds mirrored filters back onto the unique bank
  * (dW_unique[i] += flip_x(dW_full[U+i])) and ACCUMULATES into dw_unique / dbias. */
 size_t mc_wgrad_partial_bytes(const mc_conv_desc* d);
+/* One byte past the highest address a forward launch described by `d` reads through packed_w (the kernels' own indexing,
+ * restated on the host).  For every layer: mc_conv_bank_read_extent(d) <= mc_packed_weight_bytes(d, 0), and for its
+ * input-gradient launch dd: mc_conv_bank_read_extent(dd) <= mc_packed_weight_bytes(d, 1) (tests/test_abi_and_host.py). */
+size_t mc_conv_bank_read_extent(const mc_conv_desc* d);
 int mc_conv2d_wgrad(const mc_conv_desc* d, const void* x0, const void* x1, const void* dy,
                     void* partials, void* stream);
 int mc_conv2d_wgrad_finalize(const mc_conv_desc* d, const void* partials, float* dw_unique,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
     "mc_packed_weight_bytes": (_sz, [_CD, _i32]),
+    "mc_conv_bank_read_extent": (_sz, [_CD]),
     "mc_pack_weights": (C.c_int, [_CD, _vp, _i32, _vp, _vp]),
     "mc_conv_tiles": (_i32, [_CD]),
     "mc_conv_kernel_name": (C.c_char_p, [_CD]),
@@ -131,7 +132,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is a quantity, not a status code
-VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_conv_kernel_name", "mc_packed_weight_bytes", "mc_conv_tiles",
+VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_conv_kernel_name", "mc_packed_weight_bytes", "mc_conv_bank_read_extent", "mc_conv_tiles",
                    "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks", "mc_fold_blocks"}
 
 _lib = None

@@ -291,6 +291,34 @@ int mc_conv2d(const mc_conv_desc* d, const void* x0, const void* x1, const void*
   return mc_conv2d_fused(d, x0, x1, nullptr, packed_w, bias, y0, y1, stat_partials, nullptr, stream);
 }
 
+// One byte past the highest address a forward launch of `d` reads through `packed_w`, restated on the host from the indexing
+// of the kernel family that takes the launch (round 2's memory fault: the f32 kernel read 32 B past a bank whose padded
+// output-channel count is not a multiple of 16; nothing compared the kernels' reach with mc_packed_weight_bytes).
+size_t mc_conv_bank_read_extent(const mc_conv_desc* d) {
+  ConvGeom g;
+  if (geom_for(d, g)) return 0;
+  const int KK = g.K * g.K;
+  if (rr_desc(d)) {
+    // bank [chunk][output tile][fragment][lane][8]: a work-group column (grid.y) reads the NFRAG * 64 16-byte slots of its
+    // (chunk, output tile); chunks = ceil(CBin / 2), grid.y = ceil(Cout / 16)
+    const size_t nfrag = g.K == 5 ? RR<5>::NFRAG : RR<3>::NFRAG;
+    const size_t chunks = (g.CBin + 1) / 2, groups = (g.Cout + 15) / 16;
+    return (((chunks - 1) * groups + (groups - 1)) * nfrag * 64 + (nfrag * 64 - 1)) * 16 + 16;
+  }
+  if (mc_is16(g.dtype)) {
+    // bank [chunk][K-step][N-tile][lane][8]; grid.y = ceil(n_tiles / NT) work-group columns of NT tiles each
+    int chunks, steps, ntiles;
+    mc_bf16_bank_dims(g, 0, chunks, steps, ntiles);            // (ntiles = grid.y * NT: the launch's ntiles_total)
+    const size_t last = ((size_t)(chunks - 1) * steps + (steps - 1)) * ntiles + (ntiles - 1);
+    return (last * 64 + 63) * 16 + 16;
+  }
+  // f32: bank [cbin][tap][ci8][CoutP]; group cog reads columns co0 .. co0 + min(15, CoutP - 1 - co0)
+  const int ncog = (g.CoutP + 15) / 16, co0 = 16 * (ncog - 1);
+  const int comax = g.CoutP - 1 - co0;
+  const size_t last = (((size_t)(g.CBin - 1) * KK + (KK - 1)) * 8 + 7) * g.CoutP + co0 + (comax >= 15 ? 15 : comax);
+  return (last + 1) * sizeof(float);
+}
+
 size_t mc_wgrad_partial_bytes(const mc_conv_desc* d) {
   ConvGeom g;
   if (geom_for(d, g)) return 0;

@@ -298,6 +298,58 @@ def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, 
     return NetGraph(c_in, c_out, ch, [node], pad_mode=pad_mode, act=act)
 
 
+def iter_conv_descs(g: NetGraph, N: int, H: int, W: int, precision: str):
+    """(name, forward descriptor, input-gradient descriptor or None) of every convolution launch of the graph at input size
+    N x H x W -- the same shape walk and descriptors as Engine.configure, without touching a device (host-side checks:
+    tests/test_abi_and_host.py compares every launch's bank reach with the bank's size)."""
+    mc, _ = DTYPES[precision]
+    mcg = L.MC_BF16 if mc == L.MC_MIX16 else mc
+    mode = L.PAD_MODES[g.pad_mode]
+    size = {0: (H, W + 2 * g.in_pad_w)}
+    grad = {0: False}
+    for node in g.nodes:
+        if node.kind == "up":
+            size[node.out] = size[node.like] if node.like >= 0 else tuple(v * node.scale for v in size[node.src])
+            grad[node.out] = True
+            continue
+        if node.kind == "pool":
+            size[node.out] = tuple(v // node.f for v in size[node.src])
+            grad[node.out] = grad[node.src]
+            continue
+        if node.kind == "cat":
+            size[node.out] = size[node.srcs[0]]
+            grad[node.out] = True
+            continue
+        h, w = size[node.srcs[0]]
+        cs = [g.channels[i] for i in node.srcs]
+        k = node.k
+        if node.learned:
+            pad_x = k + 1 + (node.bc_x - 1) if k == 5 else k + (node.bc_x - 1)
+            pad_y = k + 1 + (node.bc_y - 1) if k == 5 else k + (node.bc_y - 1)
+            fx, fy, mh, mw = pad_x - k + 1, pad_y - k + 1, h - k + 1, w - k + 1
+            ho, wo = mh + 2 * fy, mw + 2 * fx
+            for name, (sh, sw) in dict(conv=(h, w), conv_left=(h, pad_x), conv_right=(h, pad_x), conv_bottom=(pad_y, w),
+                                       conv_top=(pad_y, w), conv_bottom_left=(pad_y, pad_x), conv_bottom_right=(pad_y, pad_x),
+                                       conv_top_left=(pad_y, pad_x), conv_top_right=(pad_y, pad_x)).items():
+                d = L.ConvDesc(N, sh, sw, cs[0], 0, node.c_out, k, 0, L.PAD_MODES["zeros"], mc, node.sym_h, 0, 0)
+                dd = L.ConvDesc(N, sh - k + 1, sw - k + 1, node.c_out, 0, cs[0], k, k - 1, 0, mcg, 0, 0, 0)
+                yield node.name + name, d, dd
+        else:
+            ho, wo = h + 2 * node.pad - k + 1, w + 2 * node.pad - k + 1
+            final_f32 = node.post == L.POST_NONE and node is g.nodes[-1] and mc != L.MC_F32 and node.c_out <= 16
+            d = L.ConvDesc(N, h, w, cs[0], cs[1] if len(cs) > 1 else 0, node.c_out, k, node.pad, mode, mc, node.sym_h, 0,
+                           int(final_f32))
+            dd = None
+            if any(grad[i] for i in node.srcs):
+                dd = L.ConvDesc(N, ho, wo, node.c_out, 0, sum(cs), k, k - 1, 0, mcg, 0, cs[0] if len(cs) > 1 else 0, 0)
+            yield node.name, d, dd
+        size[node.out] = (ho, wo)
+        grad[node.out] = True
+        if node.pool > 1:
+            size[node.pooled] = (ho // node.pool, wo // node.pool)
+            grad[node.pooled] = True
+
+
 # ------------------------------------------------------------------------------------------------
 # bicubic tap tables (nn.Upsample(mode='bicubic', align_corners=False), A = -0.75), built in f64
 # ------------------------------------------------------------------------------------------------

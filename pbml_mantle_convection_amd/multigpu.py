@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import datetime
 import os
+import sys
 import random
 import time
 from typing import Optional
@@ -117,7 +118,7 @@ class Trainer:
             if not Trainer._promotion_logged:
                 Trainer._promotion_logged = True
                 print(f"[mantle] precision 'bf16' with lambda_mom != 0 runs as '{precision}' (f16 forward tensors, bf16 "
-                      "gradients); MANTLE_MIXED=0 keeps plain bf16", flush=True)
+                      "gradients); MANTLE_MIXED=0 keeps plain bf16", file=sys.stderr, flush=True)
         if precision is not None:
             self.model_uvp.set_precision(precision)
         self.model_AD = None
@@ -229,17 +230,14 @@ class Trainer:
 
     def _check_single_mesh(self, yc):
         """The momentum residual evaluates the viscosity with ONE depth grid yc [H, W] for the whole batch (sample 0's).
-        A batch whose samples carry different grids would silently get wrong residuals.  Checked on the caller's tensor --
-        in a captured step BEFORE it is copied into the static buffer, never inside a capture -- for the first four batches
-        and every 16th after that (one host sync each; the check is not keyed on the tensor's address: the caching
-        allocator hands the next batch the same one).  A loader that fills `input_buffers()` in place passes the static
-        buffer itself and is responsible for its batches (`validate_mesh`)."""
+        A batch whose samples carry different grids would silently get wrong residuals.  Checked on EVERY batch the caller
+        hands over (one small reduction + host sync; not keyed on the tensor's address: the caching allocator hands the
+        next batch the same one) -- in a captured step BEFORE the batch is copied into the static buffer, never inside a
+        capture.  A loader that fills `input_buffers()` in place passes the static buffer itself: no copy, no check, and the
+        loader is responsible for its batches (`validate_mesh`)."""
         if yc is None or self.loss.lambda_mom == 0.0 or yc.dim() < 3 or yc.shape[0] <= 1:
             return
         if torch.cuda.is_current_stream_capturing():
-            return
-        self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
-        if self._mesh_calls > 4 and self._mesh_calls % 16:
             return
         self.validate_mesh(yc)
 

@@ -75,3 +75,22 @@ def run_rccl_single(port, outdir):
     np.savez(os.path.join(outdir, "rccl1.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_bench(rank, world, port, outdir):
+    """`bench.py --gpus 2 --backend gloo` as the driver launches it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), on a small grid; rank 0's stdout (the ONE JSON line) goes to a file."""
+    import contextlib
+    import io
+    import sys
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--steps", "3", "--warmup", "2", "--batch", "2",
+                "--size", "64", "150", "--no-cpu-baseline"]
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    with open(os.path.join(outdir, f"bench_rank{rank}.out"), "w") as f:
+        f.write(buf.getvalue())

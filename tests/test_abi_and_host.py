@@ -118,6 +118,42 @@ def test_graph_wiring_matches_layer_table():
     assert [n.name.split(".")[1] for n in cv] == [str(o[1]) for o in ops]
 
 
+def test_every_launch_reads_inside_its_filter_bank_and_workspaces():
+    """Host-side guard against out-of-bounds bank reads (round 2's GPU memory fault: the f32 kernel read 32 B past a bank whose
+    padded output-channel count is not a multiple of 16): for EVERY convolution launch of the CFG-1 / CFG-2/3 / CFG-5 / N1 /
+    N4 graphs, in every precision, the kernel family's own reach into packed_w (mc_conv_bank_read_extent, restated from the
+    kernels' indexing) stays inside mc_packed_weight_bytes, for the forward and the input-gradient bank; the partial-sum and
+    filter-gradient workspaces are sized from the same descriptors."""
+    import ctypes as C
+    from pbml_mantle_convection_amd import _lib as L
+    from pbml_mantle_convection_amd import engine as E
+    lib = L.load()
+    graphs = {
+        "cfg1 convae": (E.convae_graph(2, 3, 16, 3, act="gelu", r_p="reflect", use_symm=True, repeats=2, f=3, loss_type="mae"), 4, 128, 128),
+        "cfg3 unet": (E.unet_graph(5, 10, 16, 4, act="gelu", r_p="reflect", use_symm=True, repeats=3, f=5), 32, 506, 506),
+        "cfg5 unet 1024": (E.unet_graph(5, 10, 16, 4, act="gelu", r_p="reflect", use_symm=True, repeats=3, f=5), 1, 1024, 1024),
+        "small unet": (E.unet_graph(3, 11, 8, 4, act="gelu", r_p="zeros", use_symm=True, repeats=2, f=5), 2, 44, 70),
+        "n1 newfluidnet": (E.newfluidnet_graph(5, 7, 16, 3, act="gelu", r_p="zeros", use_symm=True, repeats=6, f=5), 32, 128, 506),
+        "n4 unet learned": (E.unet_graph(3, 10, 16, 4, act="gelu", r_p="learned", use_symm=True, repeats=2, f=5), 2, 64, 96),
+        "n4 newfluidnet learned": (E.newfluidnet_graph(3, 7, 16, 4, act="gelu", r_p="learned", use_symm=True, repeats=2, f=5), 2, 64, 96),
+    }
+    checked = 0
+    for gname, (g, N, H, W) in graphs.items():
+        for prec in ("fp32", "bf16", "mixed"):
+            for name, d, dd in E.iter_conv_descs(g, N, H, W, prec):
+                tag = (gname, prec, name)
+                nbytes = lib.mc_packed_weight_bytes(C.byref(d), 0)
+                ext = lib.mc_conv_bank_read_extent(C.byref(d))
+                assert nbytes > 0 and 0 < ext <= nbytes, (tag, "forward", ext, nbytes)
+                assert lib.mc_conv_tiles(C.byref(d)) > 0 and lib.mc_wgrad_partial_bytes(C.byref(d)) > 0, tag
+                if dd is not None:
+                    nb1 = lib.mc_packed_weight_bytes(C.byref(d), 1)
+                    ext1 = lib.mc_conv_bank_read_extent(C.byref(dd))
+                    assert nb1 > 0 and 0 < ext1 <= nb1, (tag, "input gradient", ext1, nb1)
+                checked += 1
+    assert checked > 600, checked
+
+
 def test_bicubic_tables_match_aten(golden):
     """Host-built tap tables reproduce nn.Upsample(mode='bicubic') (golden g3a/g3b) and their transposes its adjoint."""
     from pbml_mantle_convection_amd.engine import bicubic_tables

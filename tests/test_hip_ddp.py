@@ -70,3 +70,31 @@ def test_captured_step_with_a_live_rccl_process_group(tmp_path):
     one = W.steps(W.make_trainer("bf16", 100), W.global_batch(), 3)
     for k in ("grad1", "param", "m", "v"):
         assert np.array_equal(r[k], one[k]), k
+
+
+def test_bench_two_ranks_prints_one_json_line(tmp_path):
+    """`bench.py --gpus 2` end to end (the driver's multi-GPU run, rehearsed over gloo on the box's one GPU): both ranks run
+    `bench.main()` with the torchrun environment, rank 0 prints exactly one JSON line with n_gpus = 2, the whole-job value
+    and the roofline object; rank 1 prints nothing."""
+    import json
+    import ddp_worker as W
+    world = 2
+    ctx = mp.get_context("forkserver")
+    port = _free_port()
+    procs = [ctx.Process(target=W.run_bench, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+        assert p.exitcode == 0, p.exitcode
+    lines = [l for l in open(tmp_path / "bench_rank0.out").read().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
+    assert open(tmp_path / "bench_rank1.out").read().strip() == ""
