@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     p.add_argument("--size", type=int, nargs=2, default=[506, 506], metavar=("H", "W"))
     p.add_argument("--precision", type=str, default=os.environ.get("MANTLE_BENCH_PRECISION", "bf16"),
-                   choices=["bf16", "mixed", "split", "fp32"],
+                   choices=["bf16", "mixed", "fp32"],
                    help="bf16 with a momentum term runs as 'mixed' (f16 forward tensors, bf16 gradient tensors, see engine.py)")
     p.add_argument("--lambda-mom", type=float, default=1e-6, help="weight of the Stokes momentum residual (CFG-3)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
@@ -77,7 +77,7 @@ def pmc_traffic(kernel, B, H, W, precision):
     """(HBM bytes per launch of the dominant kernel, commit they were measured at) from the committed rocprofv3 PMC passes
     (FETCH_SIZE x2 + WRITE_SIZE, profiles/round3_pmc_traffic.json, collected on this same workload by tools/profile_round.sh);
     (None, None) for any other workload.  The counters cannot be read inside this process: the figure is as old as its commit."""
-    if (B, H, W) != (32, 506, 506) or precision not in ("bf16", "mixed", "split"):
+    if (B, H, W) != (32, 506, 506) or precision not in ("bf16", "mixed"):
         return None, None
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
@@ -230,9 +230,7 @@ def main():
                                    + (f", r_p={args.r_p}" if args.r_p else ""),
                        "precision": {"fp32": "fp32 storage and arithmetic", "bf16": "bf16 storage, bf16 MFMA, f32 accumulate",
                                      "mixed": "f16 storage and f16 MFMA in the forward pass, bf16 storage and bf16 MFMA for every "
-                                              "gradient tensor, f32 accumulate: the Trainer's choice for bf16 with a momentum term",
-                                     "split": "bf16 MFMA, f32 accumulate; bf16 storage except the full-resolution level of the "
-                                              "forward pass (bf16 hi+lo pairs): round 2's form of 'mixed'"}[model.precision],
+                                              "gradient tensor, f32 accumulate: the Trainer's choice for bf16 with a momentum term"}[model.precision],
                        "global_batch": world * B, "grid": [H, W], "parallelism": f"dp{world}",
                        "loss": float(loss)},
             "roofline": roof,

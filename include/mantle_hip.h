@@ -71,14 +71,8 @@ typedef struct {
                          convolution of such a layer is described with MC_BF16)       */
   int32_t sym_h;      /* number of x-mirrored filters (SymmetricConv2d symmetry['h']), 0 = plain Conv2d */
   int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
-  int32_t out_f32;    /* dtype == MC_BF16 only: 1 = write y0 as f32 CB8 (the network's last conv: u,v,p,T are not
-                         quantised to bf16); 2 = write the output as a split bf16 pair y0 = bf16(y), y1 = bf16(y - y0)
-                         (same bytes as f32; row-reuse kernel family only, else MC_EUNSUPPORTED); both require
-                         c_out <= 16 and no c_out_split */
-  int32_t w_rep_ci;   /* forward filter bank only, 0 = off.  Split-precision sources ("mixed" mode): the launch sees     */
-  int32_t w_rep_cs;   /* c_in0 + c_in1 channels but the filter tensor has w_rep_ci; the LAST w_rep_cs channels of the    */
-                      /* launch (the lo tensor) repeat the filter's last w_rep_cs channels, launch channels in           */
-                      /* [w_rep_ci, c_in0 + c_in1 - w_rep_cs) (padding of a narrow source) get zero filters              */
+  int32_t out_f32;    /* 16-bit dtypes only: 1 = write y0 as f32 CB8 (the network's last conv: u, v, p, T are not
+                         quantised); requires c_out <= 16 and no c_out_split */
 } mc_conv_desc;
 
 typedef struct {
@@ -101,12 +95,6 @@ typedef struct {
   const float* coef0; /* source 0 */
   const float* coef1; /* source 1 (second torch.cat operand) */
   int32_t act0, act1; /* MC_ACT_* */
-  /* Source 1 held in two tensors (split-precision decoder conv: [upsampled ++ hi] ++ lo would otherwise need a third
-   * operand): its first c_in1a channels (a multiple of 8) come from x1, the remaining c_in1 - c_in1a from x1b.  NULL / 0:
-   * source 1 is one tensor.  Only the row-reuse kernel family reads it (mc_conv_kernel_name(desc) starts with
-   * "k_conv_rr"); any other launch with x1b set returns MC_EUNSUPPORTED.  Forward launches only. */
-  const void* x1b;
-  int32_t c_in1a;
 } mc_conv_prologue;
 
 /* Input-gradient epilogue: the launch computes dA (gradient w.r.t. the ACTIVATED tensor a = act(GN(y))) on the padded
@@ -137,9 +125,6 @@ const char* mc_strerror(int code);
  * channel on the way in (xc/4, yc/4, dt/roll_forward). */
 int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
                  int32_t pad_mode, const float* chan_scale, int32_t dtype, void* out, void* stream);
-/* bf16, split precision ("mixed" mode): out_hi = bf16(x), out_lo = bf16(x - out_hi), both CB8 as above. */
-int mc_pack_nchw_split(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w,
-                       int32_t pad_mode, const float* chan_scale, void* out_hi, void* out_lo, void* stream);
 /* CB8 -> NCHW f32, optionally subtracting a per-(n,c) mean and cropping crop_w columns on
  * both sides ((y - mean(y))[..., 3:-3], pytorch_networks_convae.py:2024).  mean may be NULL. */
 int mc_unpack_nchw(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t crop_w,
@@ -239,22 +224,6 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
 int mc_gn_act_fwd_small(const void* y, const float* stat_partials, int32_t tiles, int32_t n, int32_t c, int32_t h, int32_t w,
                         int32_t groups, float eps, const float* gamma, const float* beta, int32_t act, int32_t pool,
                         int32_t dtype, float* stats_ng2, void* a, void* pooled, void* stream);
-/* bf16 mode, tail of the network: y is an F32 conv output (mc_conv_desc.out_f32); a = act(GN(y)) is evaluated in f32 and
- * written as two bf16 tensors a_hi = bf16(a), a_lo = bf16(a - a_hi) which the next conv reads as a two-source concat with
- * its filter bank repeated (a to ~2^-17).  y_bf16 = bf16(y) is what the backward kernels read.  Keeps the second
- * differences of the momentum residual (reference multigpu.py:186-199) above the rounding noise. */
-int mc_gn_act_split_fwd(const float* y_f32, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                        const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
-                        void* y_bf16, void* a_hi, void* a_lo, void* stream);
-/* The same from a conv output stored as a split bf16 pair (mc_conv_desc.out_f32 = 2): y = y_hi + y_lo; y_hi doubles as the
- * bf16 y of the backward pass, so only a_hi / a_lo are written (4 instead of 5 tensor passes). */
-int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                         const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
-                         void* a_hi, void* a_lo, void* stream);
-/* ... and AvgPool2d(2)(a), from the f32 values, into pooled [n][c8][h/2][w/2][8] bf16 in the same pass (w even; NULL: none). */
-int mc_gn_act_split2_pool_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                              const float* stats_ng2, const float* gamma, const float* beta, int32_t post, int32_t act,
-                              void* a_hi, void* a_lo, void* pooled, void* stream);
 /* Backward of act(GN(y)) given the gradient sources of a.  Phase 1 reduces
  * (sum dz, sum dz*yhat) per (n,c) into partials [n][blocks][c8*8][2]; phase 2 (finalize)
  * turns them into per-(n,g) means and accumulates dgamma/dbeta (in sample order: deterministic); phase 3 writes dy. */

@@ -21,7 +21,7 @@ LOSS_TYPES = {"mae": 0, "mass": 1, "curl": 2}
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "c_in0", "c_in1", "c_out", "k", "pad", "pad_mode",
-                                          "dtype", "sym_h", "c_out_split", "out_f32", "w_rep_ci", "w_rep_cs")]
+                                          "dtype", "sym_h", "c_out_split", "out_f32")]
 
 
 class GradSrc(C.Structure):
@@ -31,8 +31,7 @@ class GradSrc(C.Structure):
 
 class ConvPrologue(C.Structure):
     """mc_conv_prologue: GroupNorm affine + activation of the producer, applied by the consumer on load."""
-    _fields_ = [("coef0", C.c_void_p), ("coef1", C.c_void_p), ("act0", C.c_int32), ("act1", C.c_int32),
-                ("x1b", C.c_void_p), ("c_in1a", C.c_int32)]
+    _fields_ = [("coef0", C.c_void_p), ("coef1", C.c_void_p), ("act0", C.c_int32), ("act1", C.c_int32)]
 
 
 class ConvEpilogue(C.Structure):
@@ -58,7 +57,6 @@ SIGNATURES = {
     "mc_version": (C.c_int, []),
     "mc_strerror": (C.c_char_p, [C.c_int]),
     "mc_pack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
-    "mc_pack_nchw_split": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_unpack_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_pack_grad_nchw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "mc_sum_hw": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp]),
@@ -86,9 +84,6 @@ SIGNATURES = {
     "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
                                 _vp, _vp]),
-    "mc_gn_act_split2_pool_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "mc_gn_act_split2_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "mc_gn_act_split_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mc_gn_bwd_blocks": (_i32, [_i32, _i32]),
     "mc_gn_act_bwd_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _GS,
                                        _GS, _vp, _vp]),

@@ -56,7 +56,7 @@ __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, 
 
 // ---- batched packing: the job table travels by value in the kernel arguments (<= PK_MAX jobs per launch)
 struct PkJob {
-  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP, rep_ci, rep_cs;
+  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP;
   int dgrad, steps, ntiles, bf16, f16, rr, first_block;
   unsigned total;
   const float* w;
@@ -214,7 +214,6 @@ int mc_pack_weights(const mc_conv_desc* d, const float* w_unique, int32_t dgrad,
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!w_unique || !packed) return MC_EINVAL;
-  if (dgrad) g.rep_ci = g.rep_cs = 0;                       // (the filter repeat describes the forward bank only)
   if (bank_is_rr(g, dgrad)) return mc_rr_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   if (mc_is16(g.dtype)) return mc_bf16_pack(g, w_unique, dgrad, packed, (hipStream_t)stream);
   size_t total = mc_packed_weight_bytes(d, dgrad) / sizeof(float);
@@ -247,10 +246,6 @@ static int fill_prologue(const mc_conv_prologue* pro, ConvFuse& fz, int& rc) {
   if (!pro) return 0;
   if (!act_ok(pro->act0) || !act_ok(pro->act1)) { rc = MC_EINVAL; return 0; }
   fz.coef0 = pro->coef0; fz.coef1 = pro->coef1; fz.act0 = pro->act0; fz.act1 = pro->act1;
-  if (pro->x1b) {
-    if (pro->c_in1a <= 0 || (pro->c_in1a % 8) != 0) { rc = MC_EINVAL; return 0; }
-    fz.x1b = pro->x1b; fz.cb1a = pro->c_in1a / 8;
-  }
   return (pro->coef0 || pro->coef1 || pro->act0 != MC_ACT_NONE || pro->act1 != MC_ACT_NONE) ? 1 : 0;
 }
 
@@ -261,7 +256,6 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
   int rc = geom_for(d, g);
   if (rc) return rc;
   if (!x0 || !packed_w || !y0 || (g.Cin1 > 0 && !x1) || (g.split8 > 0 && !y1)) return MC_EINVAL;
-  if (g.out_f32 == 2 && (!y1 || !rr_desc(d) || epi)) return !y1 ? MC_EINVAL : MC_EUNSUPPORTED;   // split bf16 pair: row-reuse kernel only
   ConvFuse fz = conv_fuse_none();
   int fuse = fill_prologue(pro, fz, rc);
   if (rc) return rc;
@@ -280,7 +274,6 @@ int mc_conv2d_fused(const mc_conv_desc* d, const void* x0, const void* x1, const
     fz.estride = epi->part_stride;
     fuse = 2;
   }
-  if (fz.x1b && (!rr_desc(d) || fz.cb1a >= g.CB1 || epi)) return fz.cb1a >= g.CB1 ? MC_EINVAL : MC_EUNSUPPORTED;
   if (rr_desc(d)) return mc_conv2d_rr(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   if (mc_is16(g.dtype)) return mc_conv2d_bf16(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
   return mc_conv2d_f32(g, x0, x1, packed_w, bias, y0, y1, stat_partials, fz, fuse, (hipStream_t)stream);
@@ -334,7 +327,6 @@ int mc_conv2d_wgrad_fused(const mc_conv_desc* d, const void* x0, const void* x1,
   ConvFuse fz = conv_fuse_none();
   const int fuse = fill_prologue(pro, fz, rc);
   if (rc) return rc;
-  if (fz.x1b) return MC_EUNSUPPORTED;
   if (mc_is16(g.dtype)) return mc_wgrad_bf16(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
   return mc_wgrad_f32(g, x0, x1, dy, partials, fz, fuse, (hipStream_t)stream);
 }
@@ -397,7 +389,6 @@ int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_uni
       j.K = g.K; j.Cout = g.Cout; j.CBin = g.CBin; j.CB0 = g.CB0; j.Cin0 = g.Cin0; j.Cin1 = g.Cin1; j.Cin = g.Cin; j.U = g.U;
       j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = mc_is16(g.dtype);
       j.f16 = (g.dtype == MC_MIX16 && !j.dgrad) ? 1 : 0;       // forward banks of MC_MIX16 are f16, input-gradient banks bf16
-      j.rep_ci = j.dgrad ? 0 : g.rep_ci; j.rep_cs = j.dgrad ? 0 : g.rep_cs;
       j.rr = bank_is_rr(g, j.dgrad);
       size_t total;
       if (j.rr) {

@@ -14,7 +14,6 @@ struct ConvGeom {
   int sym_h, U;             // mirrored filters / unique filters
   int dtype;
   int out_f32;
-  int rep_ci, rep_cs;       // forward bank: filter tensor has rep_ci channels, the last rep_cs launch channels repeat its last rep_cs
 };
 
 // Device-side view of mc_conv_prologue / mc_conv_epilogue (include/mantle_hip.h): what a conv launch fuses on its input
@@ -28,14 +27,13 @@ struct ConvFuse {
   float* epart;                             // [N][tiles][CoutP][2]
   int eact, epad, ezero, ehs, ews;          // ezero: forward padding was zeros (every interior pixel is final)
   int estride;                              // slots per sample of epart
-  const void* x1b; int cb1a;                // source 1 held in two tensors: blocks [0, cb1a) from x1, the rest from x1b
   int ey16;                                 // epilogue: ey is f16 (MC_MIX16 forward tensors), else the launch's element type
 };
 static inline ConvFuse conv_fuse_none() {
   ConvFuse f;
   f.coef0 = f.coef1 = nullptr; f.act0 = f.act1 = MC_ACT_NONE;
   f.ey = nullptr; f.ecoef = nullptr; f.epart = nullptr; f.eact = MC_ACT_NONE; f.epad = 0; f.ezero = 1; f.ehs = f.ews = 0; f.estride = 0;
-  f.x1b = nullptr; f.cb1a = 0; f.ey16 = 0;
+  f.ey16 = 0;
   return f;
 }
 
@@ -87,10 +85,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.sym_h = d->sym_h; g.U = d->c_out - d->sym_h / 2;
   g.dtype = d->dtype;
   g.out_f32 = mc_is16(d->dtype) ? d->out_f32 : 0;
-  g.rep_ci = d->w_rep_ci; g.rep_cs = d->w_rep_cs;
-  if (g.rep_cs < 0 || g.rep_ci < 0 || (g.rep_cs > 0 && (g.rep_cs > g.rep_ci || g.rep_ci + g.rep_cs > g.Cin || g.sym_h < 0)))
-    return MC_EINVAL;
-  if (g.out_f32 < 0 || g.out_f32 > 2) return MC_EINVAL;
+  if (g.out_f32 < 0 || g.out_f32 > 1) return MC_EINVAL;
   if (g.out_f32 && (d->c_out > 16 || d->c_out_split != 0)) return MC_EUNSUPPORTED;
   // number of partial slabs of the filter-gradient reduction: enough workgroups to fill the chip
   // (~1024 with the other grid dimensions), bounded by 64 MiB of partials and by the work available
@@ -125,7 +120,7 @@ static __host__ __device__ inline int cin_padded_index(int ci, int Cin0, int CB0
 
 // ------------------------------------------------------------------------------------------------
 // filter-bank element generators shared by the single-layer and the batched pack kernels.
-// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP, rep_ci, rep_cs.
+// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP.
 // ------------------------------------------------------------------------------------------------
 template <typename G>
 __device__ __forceinline__ float bank_source(const G& g, const float* __restrict__ wu, int co, int cip, int ky, int kx) {
@@ -134,13 +129,7 @@ __device__ __forceinline__ float bank_source(const G& g, const float* __restrict
   bool ok = co < g.Cout && ob < g.CBin && (ob < g.CB0 ? (ob * 8 + oj < g.Cin0) : ((ob - g.CB0) * 8 + oj < g.Cin1));
   if (!ok) return 0.f;
   int ci = ob < g.CB0 ? ob * 8 + oj : g.Cin0 + (ob - g.CB0) * 8 + oj;
-  int cw = g.Cin;
-  if (g.rep_cs > 0) {                                          // split-precision sources: see mc_conv_desc.w_rep_ci
-    cw = g.rep_ci;
-    const int first_rep = g.Cin - g.rep_cs;
-    if (ci >= first_rep) ci = g.rep_ci - g.rep_cs + (ci - first_rep);
-    else if (ci >= g.rep_ci) return 0.f;
-  }
+  const int cw = g.Cin;
   int u = co, kxs = kx;
   if (co >= g.U) { u = co - g.U; kxs = g.K - 1 - kx; }        // x-mirrored copy (symmetric_layers_torch.py:121-123)
   return wu[(((size_t)u * cw + ci) * g.K + ky) * g.K + kxs];

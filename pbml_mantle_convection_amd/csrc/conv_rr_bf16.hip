@@ -161,10 +161,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
         int scb = second ? gcc - g.CB0 : gcc;
         int sC8 = second ? g.CB1 : g.CB0;
         const void* sp = second ? (const void*)x1 : (const void*)x0;
-        if (second && fz.x1b) {                              // source 1 in two tensors (mc_conv_prologue.x1b)
-          if (scb >= fz.cb1a) { sp = fz.x1b; scb -= fz.cb1a; sC8 = g.CB1 - fz.cb1a; }
-          else sC8 = fz.cb1a;
-        }
         const size_t plane_bytes = (size_t)g.H * g.W * 16;
         const char* pbase = reinterpret_cast<const char*>(sp) + ((size_t)n * sC8 + scb) * plane_bytes;
         // one descriptor per (image, channel-block plane): out-of-range offsets return zeros = zero padding / missing block
@@ -633,42 +629,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
       const size_t row_bytes = (size_t)g.Wo * 8 * esz;
       const bool colok = ox < g.Wo && cobok;
       if constexpr (OUT_F32) {
-        if (g.out_f32 == 2) {
-          // split bf16 pair instead of f32 (same bytes): y0 <- hi = bf16(y), y1 <- lo = bf16(y - hi).  hi is the tensor the
-          // backward kernels read, so the split-activation pass that follows has nothing to write for y.  Two rows at a
-          // time with the v_permlane16_swap packing of the bf16 epilogue below.
-          const size_t e0 = cb8_index(n, cbc, ty0, ox, g.CBout, g.Ho, g.Wo) * 2;
-          const size_t rb2 = (size_t)g.Wo * 16;
-          char* dh = reinterpret_cast<char*>(y0) + e0 + (size_t)(gq & 1) * rb2;
-          char* dl = reinterpret_cast<char*>(y1) + e0 + (size_t)(gq & 1) * rb2;
-          auto split2 = [](const f32x2& v, unsigned& h, unsigned& l) {
-            h = pk_bf16(v.x, v.y);
-            l = pk_bf16(v.x - __uint_as_float(h << 16), v.y - __uint_as_float(h & 0xffff0000u));
-          };
-#pragma unroll
-          for (int r = 0; r < RR_R; r += 2) {
-            const f32x2 a01 = (f32x2){acc[r][0], acc[r][1]}, a23 = (f32x2){acc[r][2], acc[r][3]};
-            const f32x2 b01 = (f32x2){acc[r + 1][0], acc[r + 1][1]}, b23 = (f32x2){acc[r + 1][2], acc[r + 1][3]};
-            if (colok && ty0 + r < g.Ho) {
-              s1[0] += a01; s1[1] += a23;
-              s2[0] = pk_fma(a01, a01, s2[0]); s2[1] = pk_fma(a23, a23, s2[1]);
-            }
-            if (colok && ty0 + r + 1 < g.Ho) {
-              s1[0] += b01; s1[1] += b23;
-              s2[0] = pk_fma(b01, b01, s2[0]); s2[1] = pk_fma(b23, b23, s2[1]);
-            }
-            unsigned ha01, la01, ha23, la23, hb01, lb01, hb23, lb23;
-            split2(a01, ha01, la01); split2(a23, ha23, la23); split2(b01, hb01, lb01); split2(b23, hb23, lb23);
-            const auto hx = __builtin_amdgcn_permlane16_swap(ha01, hb01, false, false);
-            const auto hy = __builtin_amdgcn_permlane16_swap(ha23, hb23, false, false);
-            const auto lx = __builtin_amdgcn_permlane16_swap(la01, lb01, false, false);
-            const auto ly = __builtin_amdgcn_permlane16_swap(la23, lb23, false, false);
-            if (colok && ty0 + r + (gq & 1) < g.Ho) {
-              *reinterpret_cast<uint4*>(dh + (size_t)r * rb2) = make_uint4(hx[0], hy[0], hx[1], hy[1]);
-              *reinterpret_cast<uint4*>(dl + (size_t)r * rb2) = make_uint4(lx[0], ly[0], lx[1], ly[1]);
-            }
-          }
-        } else {
+        {
 #pragma unroll
         for (int r = 0; r < RR_R; ++r) {
           const f32x2 v01 = (f32x2){acc[r][0], acc[r][1]}, v23 = (f32x2){acc[r][2], acc[r][3]};
@@ -840,7 +801,6 @@ int mc_conv2d_rr(const ConvGeom& g, const void* x0, const void* x1, const void* 
                                  (fz.act1 == MC_ACT_GELU || (fz.act1 == MC_ACT_NONE && !fz.coef1)));
   // h16: MC_MIX16 forward launch (f16 operands), or an input-gradient launch whose epilogue reads an f16 y (fz.ey16)
   const bool h16 = fuse == 2 ? fz.ey16 != 0 : g.dtype == MC_MIX16;
-  if (h16 && g.out_f32 == 2) return MC_EUNSUPPORTED;                  // (the split bf16 pair is a bf16-mode output form)
 #define RRL(K, FU, F32, GE, H) rr_launch<K, FU, F32, GE, H>(g, x0, x1, bank, bias, y0, y1, part, fz, s)
 #define RRK(K, H)                                                                                               \
   do {                                                                                                          \

@@ -28,7 +28,7 @@ __device__ __forceinline__ void split_index(size_t i, bool small, int Wd, int H,
 
 template <typename T>
 __global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int SC, int H, int W, int pad_w, int mode,
-                            const float* __restrict__ cs, T* __restrict__ out, T* __restrict__ lo) {
+                            const float* __restrict__ cs, T* __restrict__ out) {
   const int Wp = W + 2 * pad_w, C8 = (C + 7) / 8;
   size_t total = (size_t)N * C8 * H * Wp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -42,13 +42,6 @@ __global__ void k_pack_nchw(const float* __restrict__ x, int N, int C, int SC, i
       v[j] = (c < C && xs >= 0) ? x[(((size_t)n * SC + c) * H + y) * W + xs] * (cs ? cs[c] : 1.f) : 0.f;
     }
     V8<T>::st(out + i * 8, v);
-    if (lo) {            // split precision: lo = v - (what was just stored)
-      float h[8];
-      V8<T>::ld(out + i * 8, h);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = v[j] - h[j];
-      V8<T>::st(lo + i * 8, h);
-    }
   }
 }
 
@@ -372,88 +365,6 @@ __global__ __launch_bounds__(1024) void k_gn_act_small(GnArgs a, const T* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] *= 1.0f / (POOL * POOL);
       V8<T>::st(pooled + cb8_index(n, cb, by, bx, a.C8, Hp, Wp), acc);
-    }
-  }
-}
-
-// Split-precision activation of an f32 conv output (the tail of the network in bf16 mode): a = act(GN(y)) evaluated in f32
-// and stored as TWO bf16 tensors hi = bf16(a), lo = bf16(a - hi), so that the consuming conv -- which reads (hi, lo) as a
-// two-source concat with the filter bank repeated -- sees a to ~2^-17 instead of 2^-9.  Also writes bf16(y), which the
-// backward pass reads.  The momentum residual takes second differences x 126^2 of the network output: with a plain bf16
-// last hidden tensor its value is rounding noise (tests/test_hip_fullsize.py).
-__global__ void k_gn_act_split(GnArgs a, const float* __restrict__ y, bf16_t* __restrict__ yb, bf16_t* __restrict__ hi,
-                               bf16_t* __restrict__ lo) {
-  const int n = (int)blockIdx.z, cb = blockIdx.y;
-  float sc[8], sh[8];
-  gn_coef(a, n, cb, sc, sh);
-  const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
-  const size_t base = ((size_t)n * a.C8 + cb) * a.H * a.W * 8;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.H * a.W; i += gridDim.x * blockDim.x) {
-    float v[8], o[8], h[8], l[8];
-    V8<float>::ld(y + base + (size_t)i * 8, v);
-    act_fwd8<false>(v, sc, sh, act, o);
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const uint32_t p = pk_bf16(o[j], o[j + 1]);
-      h[j] = __uint_as_float(p << 16); h[j + 1] = __uint_as_float(p & 0xffff0000u);
-      l[j] = o[j] - h[j]; l[j + 1] = o[j + 1] - h[j + 1];
-    }
-    V8<bf16_t>::st(yb + base + (size_t)i * 8, v);
-    V8<bf16_t>::st(hi + base + (size_t)i * 8, h);
-    V8<bf16_t>::st(lo + base + (size_t)i * 8, l);
-  }
-}
-
-// POOL2: additionally AvgPool2d(2)(a) from the f32 values.  A thread then handles the pixels (2r, x) and (2r + 1, x), so that
-// rows stay contiguous across lanes, and the horizontal neighbour comes from the adjacent lane (needs an even width).
-template <bool POOL2>
-__global__ void k_gn_act_split2(GnArgs a, const bf16_t* __restrict__ yh, const bf16_t* __restrict__ yl, bf16_t* __restrict__ hi,
-                                bf16_t* __restrict__ lo, bf16_t* __restrict__ pooled) {
-  const int n = (int)blockIdx.z, cb = blockIdx.y;
-  float sc[8], sh[8];
-  gn_coef(a, n, cb, sc, sh);
-  const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
-  const size_t base = ((size_t)n * a.C8 + cb) * a.H * a.W * 8;
-  auto one = [&](int i, float (&o)[8]) {
-    float v[8], vl[8], h[8], l[8];
-    V8<bf16_t>::ld(yh + base + (size_t)i * 8, v);
-    V8<bf16_t>::ld(yl + base + (size_t)i * 8, vl);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += vl[j];
-    act_fwd8<false>(v, sc, sh, act, o);
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const uint32_t p = pk_bf16(o[j], o[j + 1]);
-      h[j] = __uint_as_float(p << 16); h[j + 1] = __uint_as_float(p & 0xffff0000u);
-      l[j] = o[j] - h[j]; l[j + 1] = o[j + 1] - h[j + 1];
-    }
-    V8<bf16_t>::st(hi + base + (size_t)i * 8, h);
-    V8<bf16_t>::st(lo + base + (size_t)i * 8, l);
-  };
-  if (!POOL2) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.H * a.W; i += gridDim.x * blockDim.x) {
-      float o[8];
-      one(i, o);
-    }
-  } else {
-    const int Hh = (a.H + 1) / 2, Hp = a.H / 2, Wp = a.W / 2;
-    const int total = Hh * a.W, span = gridDim.x * blockDim.x;           // (span and W are even: lanes 2k, 2k + 1 share a row)
-    for (int i0 = blockIdx.x * blockDim.x; i0 < total; i0 += span) {
-      const int i = i0 + threadIdx.x;
-      const bool live = i < total;
-      const int r = live ? i / a.W : 0, x = live ? i - r * a.W : 0;
-      float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (live) {
-        float o0[8], o1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        one(2 * r * a.W + x, o0);
-        if (2 * r + 1 < a.H) one((2 * r + 1) * a.W + x, o1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s8[j] = o0[j] + o1[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s8[j] = 0.25f * (s8[j] + __shfl_xor(s8[j], 1, 64));
-      if (live && (x & 1) == 0 && r < Hp && (x >> 1) < Wp)
-        V8<bf16_t>::st(pooled + (((size_t)n * a.C8 + cb) * Hp * Wp + (size_t)r * Wp + (x >> 1)) * 8, s8);
     }
   }
 }
@@ -1503,21 +1414,10 @@ int mc_pack_nchw(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h,
   if (pad_mode == MC_PAD_REFLECT && pad_w >= w) return MC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   size_t total = (size_t)n * ((c + 7) / 8) * h * (w + 2 * pad_w);
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_nchw<float>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (float*)out, (float*)nullptr);
-  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (bf16_t*)out, (bf16_t*)nullptr);
-  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_pack_nchw<f16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (f16_t*)out, (f16_t*)nullptr);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_pack_nchw<float>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (float*)out);
+  else if (dtype == MC_BF16) hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (bf16_t*)out);
+  else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_pack_nchw<f16_t>, grid1(total), dim3(256), 0, s, x, n, c, src_c, h, w, pad_w, pad_mode, chan_scale, (f16_t*)out);
   else return MC_EUNSUPPORTED;
-  MC_CHECK_LAUNCH();
-  return MC_OK;
-}
-
-int mc_pack_nchw_split(const float* x, int32_t n, int32_t c, int32_t src_c, int32_t h, int32_t w, int32_t pad_w, int32_t pad_mode,
-                       const float* chan_scale, void* out_hi, void* out_lo, void* stream) {
-  if (!x || !out_hi || !out_lo || n <= 0 || c <= 0 || src_c < c || h <= 0 || w <= 0 || pad_w < 0) return MC_EINVAL;
-  if (pad_mode < MC_PAD_ZEROS || pad_mode > MC_PAD_REFLECT) return MC_EINVAL;
-  size_t total = (size_t)n * ((c + 7) / 8) * h * (w + 2 * pad_w);
-  hipLaunchKernelGGL(k_pack_nchw<bf16_t>, grid1(total), dim3(256), 0, (hipStream_t)stream, x, n, c, src_c, h, w, pad_w, pad_mode,
-                     chan_scale, (bf16_t*)out_hi, (bf16_t*)out_lo);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }
@@ -1620,47 +1520,6 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   else if (dtype == MC_MIX16) { if (pool == 1) GN_LAUNCH(f16_t, 1); else if (pool == 2) GN_LAUNCH(f16_t, 2); else GN_LAUNCH(f16_t, 4); }
   else return MC_EUNSUPPORTED;
 #undef GN_LAUNCH
-  MC_CHECK_LAUNCH();
-  return MC_OK;
-}
-
-int mc_gn_act_split2_pool_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                              const float* stats, const float* gamma, const float* beta, int32_t post, int32_t act, void* a_hi,
-                              void* a_lo, void* pooled, void* stream) {
-  GnArgs a;
-  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
-  if (rc) return rc;
-  if (!y_hi || !y_lo || !a_hi || !a_lo) return MC_EINVAL;
-  if (pooled && ((w & 1) || h < 2)) return MC_EUNSUPPORTED;          // the pooled form pairs adjacent lanes: even width
-  hipStream_t s = (hipStream_t)stream;
-  if (pooled) {
-    dim3 g(max(1, min(cdiv(cdiv(h, 2) * w, 256 * 2), 4096)), a.C8, n);
-    hipLaunchKernelGGL(k_gn_act_split2<true>, g, dim3(256), 0, s, a, (const bf16_t*)y_hi, (const bf16_t*)y_lo, (bf16_t*)a_hi,
-                       (bf16_t*)a_lo, (bf16_t*)pooled);
-  } else {
-    dim3 g(max(1, min(cdiv(h * w, 256 * 4), 4096)), a.C8, n);
-    hipLaunchKernelGGL(k_gn_act_split2<false>, g, dim3(256), 0, s, a, (const bf16_t*)y_hi, (const bf16_t*)y_lo, (bf16_t*)a_hi,
-                       (bf16_t*)a_lo, (bf16_t*)nullptr);
-  }
-  MC_CHECK_LAUNCH();
-  return MC_OK;
-}
-
-int mc_gn_act_split2_fwd(const void* y_hi, const void* y_lo, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups,
-                         const float* stats, const float* gamma, const float* beta, int32_t post, int32_t act, void* a_hi,
-                         void* a_lo, void* stream) {
-  return mc_gn_act_split2_pool_fwd(y_hi, y_lo, n, c, h, w, groups, stats, gamma, beta, post, act, a_hi, a_lo, nullptr, stream);
-}
-
-int mc_gn_act_split_fwd(const float* y_f32, int32_t n, int32_t c, int32_t h, int32_t w, int32_t groups, const float* stats,
-                        const float* gamma, const float* beta, int32_t post, int32_t act, void* y_bf16, void* a_hi, void* a_lo,
-                        void* stream) {
-  GnArgs a;
-  int rc = fill_gn_args(a, n, c, h, w, groups, stats, gamma, beta, post, act);
-  if (rc) return rc;
-  if (!y_f32 || !y_bf16 || !a_hi || !a_lo) return MC_EINVAL;
-  dim3 g(max(1, min(cdiv(h * w, 256 * 4), 4096)), a.C8, n);
-  hipLaunchKernelGGL(k_gn_act_split, g, dim3(256), 0, (hipStream_t)stream, a, y_f32, (bf16_t*)y_bf16, (bf16_t*)a_hi, (bf16_t*)a_lo);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

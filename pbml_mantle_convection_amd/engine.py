@@ -23,10 +23,11 @@ import torch
 from . import _lib as L
 
 # "mixed" = MC_MIX16: every tensor of the forward pass in f16 (11 significant bits: what the momentum residual's second
-# differences need), every gradient tensor in bf16 (range), MFMA arithmetic with f32 accumulation; "split" = round 2's form
-# of the same idea (bf16 everywhere, the full-resolution level of the forward pass as bf16 (hi, lo) pairs: Engine.split0)
+# differences need), every gradient tensor in bf16 (range), MFMA arithmetic with f32 accumulation.  (Round 2's form of the
+# same idea -- bf16 everywhere, the full-resolution level of the forward pass as bf16 (hi, lo) pairs -- cost 1.1 ms per step
+# more and was removed in round 3.)
 DTYPES = {"fp32": (L.MC_F32, torch.float32), "f32": (L.MC_F32, torch.float32),
-          "bf16": (L.MC_BF16, torch.bfloat16), "mixed": (L.MC_MIX16, torch.float16), "split": (L.MC_BF16, torch.bfloat16)}
+          "bf16": (L.MC_BF16, torch.bfloat16), "mixed": (L.MC_MIX16, torch.float16)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -397,7 +398,6 @@ class _T:            # runtime tensor
     gsrcs: list = field(default_factory=list)   # gradient sources registered during backward
     # "normalise on load": the activated tensor is never materialised; consumers read the producer's raw conv output
     # `raw` and apply act(scale * y + shift) from `coef` ([N, CP, 4] table, None = activation only) while staging
-    lo: Optional[torch.Tensor] = None           # split precision ("mixed"): buf holds bf16(a), lo holds bf16(a - buf)
     fused: bool = False
     raw: Optional[torch.Tensor] = None
     coef: Optional[torch.Tensor] = None
@@ -441,12 +441,6 @@ class Engine:
         # 8.5 packed-f16 / mixed-precision instructions per element on the loader waves, beside the next stage's MFMAs,
         # instead of the ~25 f32 instructions that made the same fusion lose in round 2.
         self.fuse_dz_rr = precision == "mixed" and os.environ.get("MANTLE_FUSE_DZ_RR", "1") != "0"
-        # precision "mixed": every full-resolution tensor of the FORWARD pass (packed input, conv outputs, activations) is
-        # carried to ~16 mantissa bits -- conv outputs in f32, activations as (hi, lo) bf16 pairs that the next conv reads as
-        # two sources with its filters repeated (2 x the MFMA work of those layers; the backward pass is plain bf16).  The
-        # momentum residual takes second differences x 126^2 of the output; with 8-bit storage at the full-resolution level
-        # its value is rounding noise (2.0 x the exact value at 506^2, tests/study_bf16_momentum.py).
-        self.split0 = precision == "split"
         # GroupNorm + activation of layers with at most this many pixels run as ONE launch per direction (statistics + apply
         # forward; reduce + finalize + apply backward).  MI355X, CFG-3: 64 x 64 and 32 x 32 layers 21 -> 11 us forward and
         # 38 -> 24 us backward; 128 x 128 layers break even (25 -> 24, 49 -> 53 us: 128 blocks do not fill the chip)
@@ -493,9 +487,6 @@ class Engine:
         self.cons = cons
         self.prod = {}                       # tensor id -> plan entry of the conv that produced it (full-resolution output)
         H0, W0 = T[0].H, T[0].W
-        # split precision needs a plain conv as the consumer of the packed input
-        if self.split0 and all(c.kind == "conv" and not c.learned for c in cons[0]) and cons[0]:
-            T[0].lo = cb8(T[0].C, T[0].H, T[0].W)
         for node in g.nodes:
             if node.kind == "up":
                 s = T[node.src]
@@ -543,22 +534,7 @@ class Engine:
             final_f32 = (node.post == L.POST_NONE and node is g.nodes[-1] and self.mc_dtype != L.MC_F32
                          and node.c_out <= 16)
             ho, wo = h + 2 * node.pad - node.k + 1, w + 2 * node.pad - node.k + 1
-            # raw output in f32, activation stored as a (hi, lo) bf16 pair: full-resolution conv + (GN) + act layers
-            split_out = bool(self.split0 and node.post != L.POST_NONE and (ho, wo) == (H0, W0) and node.c_out <= 16
-                             and node.c_out % 8 == 0)
-            # sources read as (hi, lo): [split] or [plain, split] (decoder: upsampled tensor ++ skip connection); any other
-            # combination reads the hi parts only
-            lo_of = [s.lo for s in srcs]
-            hp_in = (lo_of[-1] is not None and all(x is None for x in lo_of[:-1])
-                     and (len(srcs) == 1 or srcs[0].C % 8 == 0))
-            # output of a split layer: a bf16 (hi, lo) pair straight from the row-reuse kernel's epilogue (hi is the y the backward
-            # pass reads: the split-activation pass then moves 4 instead of 5 tensors), f32 from any other kernel family
-            omode = int(final_f32 or split_out)
-            if split_out and not final_f32 and os.environ.get("MANTLE_YPAIR", "1") != "0":
-                d0 = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad, mode,
-                                self.mc_dtype, node.sym_h, 0, 0)
-                if L.load().mc_conv_kernel_name(C.byref(d0)).decode().startswith("k_conv_rr"):
-                    omode = 2
+            omode = int(final_f32)
             d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
                            mode, self.mc_dtype, node.sym_h, 0, omode)
             o = T[node.out]
@@ -579,36 +555,9 @@ class Engine:
                      part=torch.empty((N, tiles, coutp, 2), **f32),
                      bank=torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=device),
                      need_dgrad=need_dgrad)
-            if split_out:
-                e["split"] = True
-                if omode == 2:
-                    e["Ylo"] = cb8(node.c_out, ho, wo)
-                else:
-                    e["Yf"] = torch.empty((N, (node.c_out + 7) // 8, ho, wo, 8), dtype=torch.float32, device=device)
-                e["lo"] = cb8(node.c_out, ho, wo)
-                o.lo = e["lo"]
-            if hp_in:
-                # forward reads (hi, lo) as a two-source concat with the filters repeated; the gradients use `desc`
-                cs = srcs[-1].C
-                c0 = ((cs + 7) // 8) * 8 if len(srcs) == 1 else srcs[0].C + cs        # channels of source 0 of the launch
-                rep = (cin_tot, cs)          # mc_conv_desc.w_rep_ci / w_rep_cs: the bank packer repeats the filters of the split source
-                e["fdesc"] = L.ConvDesc(N, h, w, c0, cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h, 0,
-                                        omode, *rep)
-                if len(srcs) == 2:
-                    # [plain ++ hi] ++ lo: the row-reuse kernel takes source 1 in two tensors (x1 = hi, x1b = lo; bank channel
-                    # order plain, hi, lo); any other kernel family gets [plain ++ hi] materialised as one tensor
-                    # (A/B on MI355X: -0.2 ms per step against the materialised concat; MANTLE_X1B=0 selects the latter)
-                    fd3 = L.ConvDesc(N, h, w, srcs[0].C, 2 * cs, node.c_out, node.k, node.pad, mode, self.mc_dtype, node.sym_h,
-                                     0, omode, *rep)
-                    if (os.environ.get("MANTLE_X1B", "1") != "0"
-                            and L.load().mc_conv_kernel_name(C.byref(fd3)).decode().startswith("k_conv_rr")):
-                        e["fdesc"], e["x1b"] = fd3, True
-                    else:
-                        e["cat0"] = cb8(c0, h, w)
-                e["fbank"] = torch.empty(L.call("mc_packed_weight_bytes", C.byref(e["fdesc"]), 0), dtype=torch.uint8, device=device)
             fusable = all(c.kind == "up" or (c.kind == "conv" and not c.learned) for c in cons[node.out])
             o.fused = bool((self.fuse & 1) and node.post != L.POST_NONE and fusable and (cons[node.out] or node.pool > 1)
-                           and ho * wo <= self.fuse_maxpix and not split_out)
+                           and ho * wo <= self.fuse_maxpix)
             if o.fused:
                 o.raw, o.act = e["Y"], L.ACTS[g.act]
             elif node.post != L.POST_NONE:
@@ -646,7 +595,7 @@ class Engine:
                     dz_here = True
                 if (dz_here and len(srcs) == 1 and pe is not None and pe["node"].post != L.POST_NONE
                         and not pe["node"].learned and len(cons[node.srcs[0]]) == 1 and pe["node"].pool == 1
-                        and not hp_in and not pe.get("split")):
+                        ):
                     dtiles = L.call("mc_conv_tiles", C.byref(dd))
                     fblocks = L.call("mc_fold_blocks", h, w, node.pad, mode)
                     e["epi"] = pe
@@ -814,12 +763,8 @@ class Engine:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 self._pack_all_banks(params, L.stream())
-        if T[0].lo is not None:
-            L.call("mc_pack_nchw_split", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), L.ptr(T[0].buf),
-                   L.ptr(T[0].lo), st)
-        else:
-            L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
-                   L.ptr(T[0].buf), st)
+        L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
+               L.ptr(T[0].buf), st)
         if self.overlap_wgrad:
             main.wait_stream(self.side)
         else:
@@ -861,28 +806,11 @@ class Engine:
                 self._learned_forward(e, srcs[0], params, need_part, st)
             else:
                 self._probe_begin()
-                yout = e["Yf"] if "Yf" in e else e["Y"]
-                ylo = L.ptr(e["Ylo"]) if "Ylo" in e else None
-                if "fdesc" in e:       # split-precision input: (hi, lo) of the last source
-                    x0 = srcs[0].buf
-                    if "cat0" in e:
-                        ptrs = (C.c_void_p * 2)(L.ptr(srcs[0].buf), L.ptr(srcs[1].buf))
-                        cs2 = (C.c_int32 * 2)(srcs[0].C, srcs[1].C)
-                        L.call("mc_concat_cb8", ptrs, cs2, 2, N, srcs[0].H, srcs[0].W, self.mc_dtype, L.ptr(e["cat0"]), st)
-                        x0 = e["cat0"]
-                    if e.get("x1b"):
-                        pro = L.ConvPrologue(None, None, 0, 0, L.ptr(srcs[1].lo), srcs[1].C)
-                        L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(srcs[0].buf), L.ptr(srcs[1].buf), C.byref(pro),
-                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), ylo, L.ptr(e["part"]) if need_part else None, None, st)
-                    else:
-                        L.call("mc_conv2d_fused", C.byref(e["fdesc"]), L.ptr(x0), L.ptr(srcs[-1].lo), None,
-                               L.ptr(e["fbank"]), L.ptr(b), L.ptr(yout), ylo, L.ptr(e["part"]) if need_part else None, None, st)
-                else:
-                    x0, x1, pro = self._sources(srcs)
-                    L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(yout), ylo,
-                           L.ptr(e["part"]) if need_part else None, None, st)
+                x0, x1, pro = self._sources(srcs)
+                L.call("mc_conv2d_fused", C.byref(d), x0, x1, pro, L.ptr(e["bank"]), L.ptr(b), L.ptr(e["Y"]), None,
+                       L.ptr(e["part"]) if need_part else None, None, st)
                 self._probe_end(d, "fwd " + node.name)
-            small = (node.post == L.POST_GN_ACT and "pc" in e and not o.fused and not e.get("split") and node.pool in (1, 2)
+            small = (node.post == L.POST_GN_ACT and "pc" in e and not o.fused and node.pool in (1, 2)
                      and not node.learned and (self.fuse == 0 or self.fuse_dz_rr) and "dz_blocks" not in e)
             if small:
                 # statistics + activation (+ pooling) of a small layer in one launch
@@ -894,23 +822,7 @@ class Engine:
                 # (mean, rstd) per (sample, group) + the (scale, shift, mean, rstd) table consumers normalise on load with
                 L.call("mc_gn_finalize_coef", L.ptr(e["part"]), N, e["tiles"], node.c_out, node.groups, o.H * o.W, 1e-5,
                        L.ptr(gamma), L.ptr(beta), L.ptr(e["stats"]), L.ptr(e.get("coef")), st)
-            if e.get("split"):
-                pool_here = None
-                if "Ylo" in e:
-                    if node.pool == 2 and o.W % 2 == 0 and os.environ.get("MANTLE_SPLIT_POOL", "1") != "0":
-                        pool_here = T[node.pooled].buf           # AvgPool2d(2) rides in the same pass
-                    L.call("mc_gn_act_split2_pool_fwd", L.ptr(e["Y"]), L.ptr(e["Ylo"]), N, node.c_out, o.H, o.W, node.groups,
-                           L.ptr(e.get("stats")), L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(o.buf), L.ptr(e["lo"]),
-                           L.ptr(pool_here), st)
-                else:
-                    L.call("mc_gn_act_split_fwd", L.ptr(e["Yf"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
-                           L.ptr(gamma), L.ptr(beta), node.post, act, L.ptr(e["Y"]), L.ptr(o.buf), L.ptr(e["lo"]), st)
-                if node.pool > 1 and pool_here is None:
-                    # (a first form of the pooled split pass -- one thread per 2 x 2 block -- measured 0.17 ms SLOWER than this
-                    # separate pass: the block-wise access pattern halves the coalescing; the row-pair form above keeps it)
-                    L.call("mc_avgpool_fwd", L.ptr(o.buf), N, node.c_out, o.H, o.W, node.pool, self.mc_dtype,
-                           L.ptr(T[node.pooled].buf), st)
-            elif o.fused:
+            if o.fused:
                 if node.pool > 1:      # only the pooled tensor is materialised
                     L.call("mc_gn_act_fwd", L.ptr(e["Y"]), N, node.c_out, o.H, o.W, node.groups, L.ptr(e.get("stats")),
                            L.ptr(gamma), L.ptr(beta), node.post, act, node.pool, self.mc_dtype, None,
@@ -1154,10 +1066,7 @@ class Engine:
         jobs = []
         for e in self.convs:
             w = self._param(params, e["node"].name + "weight")
-            if "fdesc" in e:            # split-precision sources: the packer repeats the filters of the split source (w_rep_*)
-                jobs.append((e["fdesc"], L.ptr(w), 0, L.ptr(e["fbank"])))
-            else:
-                jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))
+            jobs.append((e["desc"], L.ptr(w), 0, L.ptr(e["bank"])))
             if e["need_dgrad"]:
                 jobs.append((e["desc"], L.ptr(w), 1, L.ptr(e["dbank"])))
         n = len(jobs)
@@ -1251,7 +1160,7 @@ class Engine:
 
     def algorithmic_bytes_per_sample(self, precision=None) -> float:
         """3 s (sum_in + sum_out over the conv layers) + s_io (C_i + 2 C_o) H W."""
-        s = 2 if (precision or self.precision) in ("bf16", "mixed", "split") else 4
+        s = 2 if (precision or self.precision) in ("bf16", "mixed") else 4
         tot = 0
         for e in self.plan:
             if e["node"].kind != "conv":

@@ -61,10 +61,9 @@ class HipNetMixin:
 
     def set_precision(self, precision: str):
         """'fp32' (parity gate: f32 storage and arithmetic), 'bf16' (bf16 storage, f32 accumulate), 'mixed' (f16 tensors in
-        the forward pass, bf16 gradient tensors: what the momentum residual needs, engine.py) or 'split' (round 2's form of
-        'mixed': bf16 with the full-resolution level of the forward pass as bf16 (hi, lo) pairs)."""
-        if precision not in ("fp32", "bf16", "mixed", "split"):
-            raise ValueError("precision must be 'fp32', 'bf16', 'mixed' or 'split'")
+        the forward pass, bf16 gradient tensors: what the momentum residual needs, engine.py)."""
+        if precision not in ("fp32", "bf16", "mixed"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'mixed'")
         self._precision = precision
         return self
 

@@ -113,8 +113,8 @@ class Trainer:
         if precision == "bf16" and lambda_mom != 0.0 and os.environ.get("MANTLE_MIXED", "1") != "0":
             # second differences x 126^2 of a network whose forward tensors carry 8 mantissa bits are rounding noise (2 x the
             # exact value at 506^2): the momentum term needs the f16 forward pass of the "mixed" mode (11 bits; gradients
-            # stay bf16).  MANTLE_MIXED=0 keeps plain bf16, MANTLE_MIXED=split selects round 2's bf16 (hi, lo) form.
-            precision = "split" if os.environ.get("MANTLE_MIXED") == "split" else "mixed"
+            # stay bf16).  MANTLE_MIXED=0 keeps plain bf16.
+            precision = "mixed"
             if not Trainer._promotion_logged:
                 Trainer._promotion_logged = True
                 print(f"[mantle] precision 'bf16' with lambda_mom != 0 runs as '{precision}' (f16 forward tensors, bf16 "
@@ -554,7 +554,7 @@ def build_arg_parser():
     p.add_argument("--data_dir", type=str, default="/plp_scr1/agar_sh/data/TPH/")
     p.add_argument("--nn_root", type=str, default="./trained_networks/")
     p.add_argument("--synthetic", type=int, nargs=3, metavar=("N", "H", "W"), default=None)
-    p.add_argument("--precision", type=str, default=None, choices=[None, "fp32", "bf16", "mixed", "split"])
+    p.add_argument("--precision", type=str, default=None, choices=[None, "fp32", "bf16", "mixed"])
     p.add_argument("--lambda_mom", type=float, default=0.0)
     p.add_argument("--use_graph", type=int, default=0)
     p.add_argument("--epochs", type=int, default=None)

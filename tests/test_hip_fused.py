@@ -303,79 +303,11 @@ def test_input_gradient_epilogue(dt, mode, c, co, k, hw, gn):
     assert err <= (2e-5 if dt == "fp32" else 1e-2) * float(ref.abs().max()), err
 
 
-@pytest.mark.parametrize("hw", [(37, 70), (20, 140)])
-def test_source_one_in_two_tensors_matches_the_materialised_concat(hw):
-    """mc_conv_prologue.x1b (row-reuse kernel): [up ++ hi] ++ lo read from three tensors == the same conv on
-    concat(up, hi) and lo — what the split-precision ("mixed") decoder conv uses; also the split activation kernel."""
-    from pbml_mantle_convection_amd import _lib as L
-    lib = L.load()
-    N, (H, W), C0, CS, CO, K = 2, hw, 16, 16, 16, 5
-    g = torch.Generator().manual_seed(7)
-    up = _cb8(torch.randn((N, C0, H, W), generator=g), torch.bfloat16)
-    a = torch.randn((N, CS, H, W), generator=g)
-    hi_f = a.to(torch.bfloat16).float()
-    hi, lo = _cb8(hi_f, torch.bfloat16), _cb8(a - hi_f, torch.bfloat16)
-    w = (torch.randn((CO, C0 + CS, K, K), generator=g) * 0.05).to(DEV)
-    w2 = torch.cat([w, w[:, C0:]], 1).contiguous()
-    bias = torch.randn(CO, generator=g).to(DEV)
-    st = L.stream()
-
-    def run(desc, x0, x1, pro, wt=None):
-        assert L.call("mc_conv_tiles", C.byref(desc)) > 0
-        bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(desc), 0), dtype=torch.uint8, device=DEV)
-        L.call("mc_pack_weights", C.byref(desc), L.ptr(w2 if wt is None else wt), 0, L.ptr(bank), st)
-        y = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.float32, device=DEV)
-        L.call("mc_conv2d_fused", C.byref(desc), L.ptr(x0), L.ptr(x1), pro, L.ptr(bank), L.ptr(bias), L.ptr(y), None, None, None, st)
-        torch.cuda.synchronize()
-        return y
-
-    d3 = L.ConvDesc(N, H, W, C0, 2 * CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
-    assert lib.mc_conv_kernel_name(C.byref(d3)).decode().startswith("k_conv_rr")
-    pro = L.ConvPrologue(None, None, 0, 0, L.ptr(lo), CS)
-    y3 = run(d3, up, hi, C.byref(pro))
-    cat0 = torch.cat([up, hi], 1).contiguous()
-    d2 = L.ConvDesc(N, H, W, C0 + CS, CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
-    y2 = run(d2, cat0, lo, None)
-    assert torch.equal(y3, y2)
-    # the bank packer repeats the split source's filters itself (mc_conv_desc.w_rep_ci / w_rep_cs): same result from the
-    # network's own 32-channel filter tensor, single launches and the batched packer alike
-    d3r = L.ConvDesc(N, H, W, C0, 2 * CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1, C0 + CS, CS)
-    assert torch.equal(run(d3r, up, hi, C.byref(pro), wt=w), y3)
-    bank_a = torch.zeros(L.call("mc_packed_weight_bytes", C.byref(d3r), 0), dtype=torch.uint8, device=DEV)
-    bank_b = torch.zeros_like(bank_a)
-    L.call("mc_pack_weights", C.byref(d3), L.ptr(w2), 0, L.ptr(bank_a), st)
-    L.call("mc_pack_weights_batched", (L.ConvDesc * 1)(d3r), (C.c_void_p * 1)(L.ptr(w)), (C.c_int32 * 1)(0), (C.c_void_p * 1)(L.ptr(bank_b)), 1, st)
-    torch.cuda.synchronize()
-    assert torch.equal(bank_a, bank_b)
-    # and against fp64 on the same (hi + lo) operand: the pair carries a to ~2^-17
-    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(torch.cat([_from_cb8(up, C0), hi_f + _from_cb8(lo, CS)], 1).double(),
-                                                             (2, 2, 2, 2), mode="reflect"),
-                                     w.cpu().to(torch.bfloat16).double(), bias.cpu().double())
-    assert float((_from_cb8(y3, CO).double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
-    # a launch that cannot honour x1b must refuse it
-    dsmall = L.ConvDesc(N, 12, 20, C0, 2 * CS, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 1)
-    if not lib.mc_conv_kernel_name(C.byref(dsmall)).decode().startswith("k_conv_rr"):
-        bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(dsmall), 0), dtype=torch.uint8, device=DEV)
-        rc = lib.mc_conv2d_fused(C.byref(dsmall), L.ptr(up), L.ptr(hi), C.byref(pro), L.ptr(bank), L.ptr(bias), L.ptr(y3), None, None,
-                                 None, st)
-        assert rc == -2, rc
-
-    # the split activation: hi + lo carries act(y) to ~2^-17, y_bf16 is the rounded raw output
-    yf = torch.randn((N, CS // 8, H, W, 8), generator=g).to(DEV)
-    yb, h_, l_ = (torch.zeros((N, CS // 8, H, W, 8), dtype=torch.bfloat16, device=DEV) for _ in range(3))
-    L.call("mc_gn_act_split_fwd", L.ptr(yf), N, CS, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(yb), L.ptr(h_),
-           L.ptr(l_), st)
-    torch.cuda.synchronize()
-    act = torch.nn.functional.gelu(_from_cb8(yf, CS).double())
-    assert float((_from_cb8(h_, CS).double() + _from_cb8(l_, CS).double() - act).abs().max()) <= 3e-4
-    assert torch.equal(yb, yf.to(torch.bfloat16))
-
-
 @pytest.mark.parametrize("kind", ["unet", "unet16", "convae", "newfluidnet"])
 def test_mixed_precision_mode_on_every_graph(kind):
-    """precision='mixed' (split-precision full-resolution level) on graphs with pooled / concatenated / upsampled consumers of
-    the split tensors (they read the hi part): forward and every parameter gradient stay as close to the fp32 execution as the
-    plain bf16 mode is (the split can only remove rounding), and the U-Net output gets closer."""
+    """precision='mixed' (f16 forward tensors, bf16 gradient tensors) on every graph family -- pooled / concatenated /
+    upsampled tensors, 3 x 3 and 5 x 5 layers: forward and every parameter gradient are at least as close to the fp32 execution
+    as the plain bf16 mode is, and the network output is closer (11 instead of 8 significant bits in every forward tensor)."""
     from pbml_mantle_convection_amd.pytorch_networks_convae import NewFluidNet
     res = {}
     for prec in ("fp32", "bf16", "mixed"):
@@ -397,68 +329,4 @@ def test_mixed_precision_mode_on_every_graph(kind):
         e_bf = rel_l2(res["bf16"][j], res["fp32"][j])
         e_mx = rel_l2(res["mixed"][j], res["fp32"][j])
         assert e_mx <= 1.25 * e_bf + 1e-3, (kind, what, e_mx, e_bf)
-    if kind.startswith("unet"):
-        assert rel_l2(res["mixed"][0], res["fp32"][0]) < rel_l2(res["bf16"][0], res["fp32"][0])
-
-
-def test_conv_output_as_split_bf16_pair():
-    """mc_conv_desc.out_f32 = 2 (row-reuse kernel): y0 + y1 reproduces the f32 output of the same launch to ~2^-17, y0 is the
-    bf16 rounding of it, the GroupNorm partial sums are identical; mc_gn_act_split2_fwd on the pair == mc_gn_act_split_fwd on
-    the f32 tensor; any other kernel family refuses the mode."""
-    from pbml_mantle_convection_amd import _lib as L
-    lib = L.load()
-    N, H, W, CI, CO, K = 2, 37, 70, 16, 16, 5
-    g = torch.Generator().manual_seed(21)
-    x = _cb8(torch.randn((N, CI, H, W), generator=g), torch.bfloat16)
-    w = (torch.randn((CO, CI, K, K), generator=g) * 0.05).to(DEV)
-    bias = torch.randn(CO, generator=g).to(DEV)
-    st = L.stream()
-    outs = {}
-    for mode in (1, 2):
-        d = L.ConvDesc(N, H, W, CI, 0, CO, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, mode)
-        assert lib.mc_conv_kernel_name(C.byref(d)).decode().startswith("k_conv_rr")
-        tiles = L.call("mc_conv_tiles", C.byref(d))
-        bank = torch.empty(L.call("mc_packed_weight_bytes", C.byref(d), 0), dtype=torch.uint8, device=DEV)
-        L.call("mc_pack_weights", C.byref(d), L.ptr(w), 0, L.ptr(bank), st)
-        part = torch.zeros((N, tiles, CO, 2), dtype=torch.float32, device=DEV)
-        if mode == 1:
-            y = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.float32, device=DEV)
-            L.call("mc_conv2d_fused", C.byref(d), L.ptr(x), None, None, L.ptr(bank), L.ptr(bias), L.ptr(y), None, L.ptr(part), None, st)
-            outs[mode] = (y, part)
-        else:
-            yh = torch.zeros((N, CO // 8, H, W, 8), dtype=torch.bfloat16, device=DEV)
-            yl = torch.zeros_like(yh)
-            L.call("mc_conv2d_fused", C.byref(d), L.ptr(x), None, None, L.ptr(bank), L.ptr(bias), L.ptr(yh), L.ptr(yl), L.ptr(part), None, st)
-            outs[mode] = (yh, yl, part)
-            rc = lib.mc_conv2d_fused(C.byref(d), L.ptr(x), None, None, L.ptr(bank), L.ptr(bias), L.ptr(yh), None, L.ptr(part), None, st)
-            assert rc == -1                                   # the pair needs both tensors
-    torch.cuda.synchronize()
-    yf, p1 = outs[1]
-    yh, yl, p2 = outs[2]
-    assert torch.equal(p1, p2)
-    assert torch.equal(yh, yf.to(torch.bfloat16))
-    err = (yh.float() + yl.float() - yf).abs().max()
-    assert float(err) <= 2.0 ** -16 * float(yf.abs().max())
-    # split activation from the pair == from the f32 tensor (same f32 value up to the pair's 2^-17)
-    a1 = [torch.zeros_like(yh) for _ in range(3)]
-    a2 = [torch.zeros_like(yh) for _ in range(2)]
-    L.call("mc_gn_act_split_fwd", L.ptr(yf), N, CO, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(a1[0]), L.ptr(a1[1]),
-           L.ptr(a1[2]), st)
-    L.call("mc_gn_act_split2_fwd", L.ptr(yh), L.ptr(yl), N, CO, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(a2[0]),
-           L.ptr(a2[1]), st)
-    torch.cuda.synchronize()
-    s1 = a1[1].float() + a1[2].float()
-    s2 = a2[0].float() + a2[1].float()
-    assert float((s1 - s2).abs().max()) <= 3e-5 * max(1.0, float(s1.abs().max()))
-    # the pooled form of the pass: same hi / lo, AvgPool2d(2) of the f32 activation
-    a3 = [torch.zeros_like(yh) for _ in range(2)]
-    pl = torch.zeros((N, CO // 8, H // 2, W // 2, 8), dtype=torch.bfloat16, device=DEV)
-    L.call("mc_gn_act_split2_pool_fwd", L.ptr(yh), L.ptr(yl), N, CO, H, W, 1, None, None, None, L.POST_ACT, L.ACTS["gelu"], L.ptr(a3[0]),
-           L.ptr(a3[1]), L.ptr(pl), st)
-    torch.cuda.synchronize()
-    assert torch.equal(a3[0], a2[0]) and torch.equal(a3[1], a2[1])
-    pref = torch.nn.functional.avg_pool2d(torch.nn.functional.gelu(_from_cb8(yh, CO).double() + _from_cb8(yl, CO).double()), 2)
-    assert float((_from_cb8(pl, CO).double() - pref).abs().max()) <= 1e-2 * float(pref.abs().max())
-    # more than 16 output channels: the mode is refused like the f32 output is
-    dsm = L.ConvDesc(N, H, W, CI, 0, 32, K, K // 2, L.PAD_MODES["reflect"], L.MC_BF16, 0, 0, 2)
-    assert L.call("mc_conv_tiles", C.byref(dsm)) <= 0
+    assert rel_l2(res["mixed"][0], res["fp32"][0]) < 0.5 * rel_l2(res["bf16"][0], res["fp32"][0])
