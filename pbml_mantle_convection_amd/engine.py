@@ -1030,7 +1030,7 @@ class Engine:
                     self._probe_begin()
                     L.call("mc_conv2d_fused", C.byref(e["ddesc"]), L.ptr(dY), None, None, L.ptr(e["dbank"]), None,
                            L.ptr(dxp[0]), None, None, C.byref(epi), st)
-                    self._probe_end(e["ddesc"], "dgrad " + node.name)
+                    self._probe_end(e["ddesc"], "dgrad+dz " + node.name, extra_in=s0.C * s0.H * s0.W)
                     L.call("mc_fold_padded_dz", L.ptr(dxp[0]), N, s0.C, s0.H, s0.W, node.pad, self.mode, self.mc_dtype,
                            L.ptr(pe["Y"]), coef, act, L.ptr(pe["dz_part"]), pe["dz_blocks"], pe["dz_tiles"], st)
                     pe["dz"] = L.GradSrc(L.ptr(dxp[0]), L.GSRC_PADFOLD, node.pad, self.mode, 1, s0.H, s0.W)
@@ -1106,13 +1106,14 @@ class Engine:
         if self._probe is not None:
             self._probe_ev = self._probe_event()
 
-    def _probe_end(self, d, label):
+    def _probe_end(self, d, label, extra_in=0):
+        """extra_in: further algorithmic input elements per sample (the producer's y an epilogue-fused launch reads once)."""
         if self._probe is not None:
             ev = self._probe_event()
             es = torch.tensor([], dtype=self.t_dtype).element_size()       # (forward and gradient tensors have the same width)
             ho, wo = d.h + 2 * d.pad - d.k + 1, d.w + 2 * d.pad - d.k + 1
             cin = d.c_in0 + d.c_in1
-            nbytes = d.n * es * (cin * d.h * d.w + d.c_out * ho * wo)          # algorithmic: read input once, write output once
+            nbytes = d.n * es * (cin * d.h * d.w + d.c_out * ho * wo + extra_in)   # algorithmic: read inputs once, write output once
             flops = 2.0 * d.n * cin * d.c_out * d.k * d.k * ho * wo
             name = L.load().mc_conv_kernel_name(C.byref(d)).decode()
             shape = f"{label.split()[0]} {cin}->{d.c_out} k{d.k} {d.n}x{d.h}x{d.w}"
