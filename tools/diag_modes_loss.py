@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 batch = [t.to(dev) for t in synthetic_batch(B, H, W, 1234, p_pred=True, device="cpu")]
 gVTp, uvp, scaler, paras, yc = batch
 ref = None
-for prec in ("fp32", "mixed", "split", "bf16"):
+for prec in ("fp32", "mixed", "bf16"):
     torch.manual_seed(0)
     m = Unet(5, 10, 16, 4, dev, "gelu", "reflect", "mass", use_symm=True, repeats=3, f=5, p_pred=True)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
