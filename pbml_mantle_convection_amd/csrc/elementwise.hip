@@ -299,6 +299,44 @@ __global__ void k_gn_act_fwd(GnArgs a, const T* __restrict__ y, T* __restrict__ 
   }
 }
 
+// a = act(GN(y)) and AvgPool2d(2)(a) with COALESCED rows: a thread handles the pixels (2r, x) and (2r + 1, x), so consecutive
+// lanes read and write consecutive 16-byte vectors, and takes the horizontal neighbour's sums from the adjacent lane (needs an
+// even width; the one-thread-per-2x2-block form above touches every second vector of a row per instruction: 182 us instead
+// of ~125 us at 506 x 512).  Pooling uses the f32 activation values, like the block form.
+template <typename T>
+__global__ void k_gn_act_fwd_pool2_rows(GnArgs a, const T* __restrict__ y, T* __restrict__ out, T* __restrict__ pooled) {
+  const int n = (int)blockIdx.z, cb = blockIdx.y;
+  float sc[8], sh[8];
+  gn_coef(a, n, cb, sc, sh);
+  const int act = a.post == MC_POST_NONE ? MC_ACT_NONE : a.act;
+  const size_t base = ((size_t)n * a.C8 + cb) * a.H * a.W * 8;
+  const int Hh = (a.H + 1) / 2, Hp = a.H / 2, Wp = a.W / 2;
+  const int total = Hh * a.W, span = gridDim.x * blockDim.x;             // (span and W are even: lanes 2k, 2k + 1 share a row)
+  for (int i0 = blockIdx.x * blockDim.x; i0 < total; i0 += span) {
+    const int i = i0 + threadIdx.x;
+    const bool live = i < total;
+    const int r = live ? i / a.W : 0, x = live ? i - r * a.W : 0;
+    float s8[8], v0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      const size_t i0e = base + ((size_t)(2 * r) * a.W + x) * 8;
+      V8<T>::ld(y + i0e, v0);
+      act_fwd8<FastMath<T>::value>(v0, sc, sh, act, v0);
+      if (out) V8<T>::st(out + i0e, v0);
+      if (2 * r + 1 < a.H) {
+        V8<T>::ld(y + i0e + (size_t)a.W * 8, v1);
+        act_fwd8<FastMath<T>::value>(v1, sc, sh, act, v1);
+        if (out) V8<T>::st(out + i0e + (size_t)a.W * 8, v1);
+      }
+    }
+    // ((a00 + a01) + a10) + a11: the summation order of the block form, of k_gn_act_small and of k_avgpool (bit-identical
+    // pooled tensors whichever kernel a layer takes)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] = 0.25f * (((v0[j] + __shfl_xor(v0[j], 1, 64)) + v1[j]) + __shfl_xor(v1[j], 1, 64));
+    if (live && (x & 1) == 0 && r < Hp && (x >> 1) < Wp)
+      V8<T>::st(pooled + (((size_t)n * a.C8 + cb) * Hp * Wp + (size_t)r * Wp + (x >> 1)) * 8, s8);
+  }
+}
+
 // Small layers: GroupNorm statistics from the conv's partial sums AND a = act(GN(y)) [+ AvgPool] in one launch, one block per
 // (sample, channel block); needs every group inside one channel block (channels per group 1, 2, 4 or 8).  The (mean, rstd)
 // pairs are also written out for the backward pass.  Same f64 sums and f32 expressions as k_gn_finalize / gn_coef.
@@ -1079,24 +1117,27 @@ template <typename T, int BYT, int BXT>
 __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int Hi, int Wi, const int* __restrict__ tys,
                                                      const int* __restrict__ tyj, const float* __restrict__ tyw,
                                                      const int* __restrict__ txs, const int* __restrict__ txj,
-                                                     const float* __restrict__ txw, T* __restrict__ dx, int tiles_x) {
+                                                     const float* __restrict__ txw, T* __restrict__ dx, int tiles_x, int tiles) {
   __shared__ __attribute__((aligned(16))) T win[BWIN * BWIN * 8];
   __shared__ float4 tmp[2][BT][BWIN];
   __shared__ int s_yj[BT][BYT];
   __shared__ float s_yw[BT][BYT];
   const int n = blockIdx.z, cb = blockIdx.y;
-  const int ty0 = (blockIdx.x / tiles_x) * BT, tx0 = (blockIdx.x % tiles_x) * BT;
-  const int ty1 = min(ty0 + BT, Hi), tx1 = min(tx0 + BT, Wi);
-  // output ranges referenced by this tile: the transposed tap lists are sorted by output index and monotone in the
-  // input index, so the range starts at the first entry of the first row's list (uniform scalar loads)
-  const int ylo = tyj[tys[ty0]], xlo = txj[txs[tx0]];
-  // ---- stage the window raw (all loads of a thread in flight together), the y tap lists and this thread's x taps
-  {
-    constexpr int VPT = (BWIN * BWIN + 255) / 256, Q = sizeof(T) == 4 ? 2 : 1;
-    const int pad = g.kind == MC_GSRC_PLAIN ? 0 : g.pad;
-    const int hs = g.hs + 2 * pad, ws = g.ws + 2 * pad;
-    const T* base = reinterpret_cast<const T*>(g.ptr);
-    uint4 rv[VPT][Q];
+  constexpr int VPT = (BWIN * BWIN + 255) / 256, Q = sizeof(T) == 4 ? 2 : 1;
+  const int pad = g.kind == MC_GSRC_PLAIN ? 0 : g.pad;
+  const int hs = g.hs + 2 * pad, ws = g.ws + 2 * pad;
+  const T* base = reinterpret_cast<const T*>(g.ptr);
+  // Round 3: blocks are PERSISTENT over the tiles of their (sample, channel block) and the raw window of tile t + 1 is in
+  // flight (registers) while tile t runs its two passes: one block per tile exposed the load latency once per tile with only
+  // three blocks resident per CU (45 KB of LDS each).
+  uint4 rv[VPT][Q];
+  auto window_origin = [&](int tile, int& ty0, int& tx0, int& ylo, int& xlo) {
+    ty0 = (tile / tiles_x) * BT; tx0 = (tile % tiles_x) * BT;
+    // output ranges referenced by this tile: the transposed tap lists are sorted by output index and monotone in the
+    // input index, so the range starts at the first entry of the first row's list (uniform scalar loads)
+    ylo = tyj[tys[ty0]]; xlo = txj[txs[tx0]];
+  };
+  auto load_window = [&](int ylo, int xlo) {
 #pragma unroll
     for (int m = 0; m < VPT; ++m) {
       int i = threadIdx.x + m * 256;
@@ -1110,6 +1151,15 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
         rv[m][q] = ok ? v : make_uint4(0, 0, 0, 0);
       }
     }
+  };
+  int tile = blockIdx.x;
+  if (tile >= tiles) return;
+  int ty0, tx0, ylo, xlo;
+  window_origin(tile, ty0, tx0, ylo, xlo);
+  load_window(ylo, xlo);
+  for (; tile < tiles; tile += gridDim.x) {
+    const int ty1 = min(ty0 + BT, Hi), tx1 = min(tx0 + BT, Wi);
+    // ---- the y tap lists, this thread's x taps, the staged window -> LDS
     if (threadIdx.x < BT * BYT) {
       int ly = threadIdx.x / BYT, k = threadIdx.x - ly * BYT;
       int yi = min(ty0 + ly, Hi - 1);
@@ -1126,65 +1176,73 @@ __global__ __launch_bounds__(256) void k_bicubic_bwd(mc_grad_src g, int C8, int 
 #pragma unroll
         for (int q = 0; q < Q; ++q) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(&win[i * 8]) + 16 * q) = rv[m][q];
     }
-  }
-  const int ly = threadIdx.x / BT, lx = threadIdx.x % BT;                            // x pass: one thread per pixel
-  const int yi = min(ty0 + ly, Hi - 1), xi = min(tx0 + lx, Wi - 1);
-  const int a0 = tys[yi], a1 = tys[yi + 1], b0 = txs[xi], nb = txs[xi + 1] - b0;
-  int xj[BXT];
-  float xw[BXT];
+    const int ly = threadIdx.x / BT, lx = threadIdx.x % BT;                            // x pass: one thread per pixel
+    const int yi = min(ty0 + ly, Hi - 1), xi = min(tx0 + lx, Wi - 1);
+    const int a0 = tys[yi], a1 = tys[yi + 1], b0 = txs[xi], nb = txs[xi + 1] - b0;
+    int xj[BXT];
+    float xw[BXT];
 #pragma unroll
-  for (int k = 0; k < BXT; ++k) {
-    xj[k] = k < nb ? txj[b0 + k] - xlo : 0;
-    xw[k] = k < nb ? txw[b0 + k] : 0.f;
-  }
-  bool fast = a1 - a0 <= BYT && nb <= BXT && (a1 == a0 || (tyj[a0] - ylo >= 0 && tyj[a1 - 1] - ylo < BWIN));
-#pragma unroll
-  for (int k = 0; k < BXT; ++k) {
-    fast = fast && xj[k] >= 0 && xj[k] < BWIN;
-    xj[k] = min(max(xj[k], 0), BWIN - 1);
-  }
-  __syncthreads();
-  // y pass: tmp[ly][c] = sum_a w_a win[yo_a - ylo][c]
-  for (int i = threadIdx.x; i < BT * BWIN; i += 256) {
-    int py = i / BWIN, c = i - py * BWIN;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < BYT; ++k) {
-      int r = s_yj[py][k];
-      float wa = s_yw[py][k];
-      float v[8];
-      V8<T>::ld(&win[(r * BWIN + c) * 8], v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wa * v[j];
+    for (int k = 0; k < BXT; ++k) {
+      xj[k] = k < nb ? txj[b0 + k] - xlo : 0;
+      xw[k] = k < nb ? txw[b0 + k] : 0.f;
     }
-    tmp[0][py][c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    tmp[1][py][c] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-  }
-  __syncthreads();
-  if (ty0 + ly >= ty1 || tx0 + lx >= tx1) return;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (fast) {
+    bool fast = a1 - a0 <= BYT && nb <= BXT && (a1 == a0 || (tyj[a0] - ylo >= 0 && tyj[a1 - 1] - ylo < BWIN));
 #pragma unroll
-    for (int k = 0; k < BXT; ++k) {                         // dead entries: index 0, weight 0
-      float w = xw[k];
-      float4 p0 = tmp[0][ly][xj[k]], p1 = tmp[1][ly][xj[k]];
-      acc[0] += w * p0.x; acc[1] += w * p0.y; acc[2] += w * p0.z; acc[3] += w * p0.w;
-      acc[4] += w * p1.x; acc[5] += w * p1.y; acc[6] += w * p1.z; acc[7] += w * p1.w;
+    for (int k = 0; k < BXT; ++k) {
+      fast = fast && xj[k] >= 0 && xj[k] < BWIN;
+      xj[k] = min(max(xj[k], 0), BWIN - 1);
     }
-  } else {
-    for (int a = a0; a < a1; ++a) {
-      int yo = tyj[a];
-      float wa = tyw[a];
-      for (int b = b0; b < b0 + nb; ++b) {
-        float w = wa * txw[b];
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
+    __syncthreads();
+    // the next tile's window: in flight during both passes
+    const int cty0 = ty0, ctx0 = tx0;
+    if (tile + (int)gridDim.x < tiles) {
+      window_origin(tile + gridDim.x, ty0, tx0, ylo, xlo);
+      load_window(ylo, xlo);
+    }
+    // y pass: tmp[ly][c] = sum_a w_a win[yo_a - ylo][c]
+    for (int i = threadIdx.x; i < BT * BWIN; i += 256) {
+      int py = i / BWIN, c = i - py * BWIN;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+      for (int k = 0; k < BYT; ++k) {
+        int r = s_yj[py][k];
+        float wa = s_yw[py][k];
+        float v[8];
+        V8<T>::ld(&win[(r * BWIN + c) * 8], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wa * v[j];
       }
+      tmp[0][py][c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      tmp[1][py][c] = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
+    __syncthreads();
+    if (cty0 + ly < ty1 && ctx0 + lx < tx1) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (fast) {
+#pragma unroll
+        for (int k = 0; k < BXT; ++k) {                         // dead entries: index 0, weight 0
+          float w = xw[k];
+          float4 p0 = tmp[0][ly][xj[k]], p1 = tmp[1][ly][xj[k]];
+          acc[0] += w * p0.x; acc[1] += w * p0.y; acc[2] += w * p0.z; acc[3] += w * p0.w;
+          acc[4] += w * p1.x; acc[5] += w * p1.y; acc[6] += w * p1.z; acc[7] += w * p1.w;
+        }
+      } else {
+        for (int a = a0; a < a1; ++a) {
+          int yo = tyj[a];
+          float wa = tyw[a];
+          for (int b = b0; b < b0 + nb; ++b) {
+            float w = wa * txw[b];
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            grad_fetch_add<T>(g, n, cb, yo, txj[b], C8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+          }
+        }
+      }
+      V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
+    }
+    __syncthreads();                                       // tmp / win / the tap lists are rewritten by the next tile
   }
-  V8<T>::st(dx + cb8_index(n, cb, yi, xi, C8, Hi, Wi), acc);
 }
 
 // (Round 3 tried a streaming form -- wave = input row, lanes over the output columns, the row's transposed tap list summed
@@ -1514,6 +1572,14 @@ int mc_gn_act_fwd(const void* y, int32_t n, int32_t c, int32_t h, int32_t w, int
   hipStream_t s = (hipStream_t)stream;
   int per = cdiv(h, pool) * cdiv(w, pool);
   dim3 g(max(1, min(cdiv(per, 256 * gn_fwd_vpt()), 4096)), a.C8, n);
+  if (pool == 2 && (w & 1) == 0 && h >= 2 && dtype != MC_F32) {     // row-pair form (16-bit types: one 16-byte vector per pixel)
+    dim3 gp(max(1, min(cdiv(cdiv(h, 2) * w, 256 * 2), 4096)), a.C8, n);
+    if (dtype == MC_BF16) hipLaunchKernelGGL(k_gn_act_fwd_pool2_rows<bf16_t>, gp, dim3(256), 0, s, a, (const bf16_t*)y, (bf16_t*)a_out, (bf16_t*)pooled);
+    else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_gn_act_fwd_pool2_rows<f16_t>, gp, dim3(256), 0, s, a, (const f16_t*)y, (f16_t*)a_out, (f16_t*)pooled);
+    else return MC_EUNSUPPORTED;
+    MC_CHECK_LAUNCH();
+    return MC_OK;
+  }
 #define GN_LAUNCH(T, P) hipLaunchKernelGGL((k_gn_act_fwd<T, P>), g, dim3(256), 0, s, a, (const T*)y, (T*)a_out, (T*)pooled)
   if (dtype == MC_F32) { if (pool == 1) GN_LAUNCH(float, 1); else if (pool == 2) GN_LAUNCH(float, 2); else GN_LAUNCH(float, 4); }
   else if (dtype == MC_BF16) { if (pool == 1) GN_LAUNCH(bf16_t, 1); else if (pool == 2) GN_LAUNCH(bf16_t, 2); else GN_LAUNCH(bf16_t, 4); }
@@ -1871,9 +1937,12 @@ int mc_bicubic_bwd_taps(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi,
   int C8 = (c + 7) / 8;
   hipStream_t s = (hipStream_t)stream;
   int tiles_x = cdiv(wi, BT), tiles_y = cdiv(hi, BT);
-  dim3 g(tiles_x * tiles_y, C8, n);
+  // persistent blocks: ~6 resident per CU over the (tile, channel block, sample) grid, several tiles each
+  static const int per_cu = env_int("MC_BICUBIC_BLOCKS_PER_CU", 6);
+  const int want = max(1, (256 * per_cu) / max(1, C8 * n));
+  dim3 g(min(tiles_x * tiles_y, want), C8, n);
   const bool y8 = max_taps_y > 0 && max_taps_y <= 8, x8 = max_taps_x > 0 && max_taps_x <= 8;
-#define BW(T, A, B) hipLaunchKernelGGL((k_bicubic_bwd<T, A, B>), g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (T*)dx, tiles_x)
+#define BW(T, A, B) hipLaunchKernelGGL((k_bicubic_bwd<T, A, B>), g, dim3(256), 0, s, *gs, C8, hi, wi, tys, tyj, tyw, txs, txj, txw, (T*)dx, tiles_x, tiles_x * tiles_y)
 #define BWT(T) do { if (y8 && x8) BW(T, 8, 8); else if (y8) BW(T, 8, 12); else if (x8) BW(T, 12, 8); else BW(T, 12, 12); } while (0)
   if (dtype == MC_F32) BWT(float);
   else if (mc_is16(dtype)) BWT(bf16_t);
