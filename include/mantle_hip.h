@@ -73,6 +73,9 @@ typedef struct {
   int32_t c_out_split;/* dgrad only: first c_out_split output channels go to y0, the rest to y1 (0 = all to y0) */
   int32_t out_f32;    /* 16-bit dtypes only: 1 = write y0 as f32 CB8 (the network's last conv: u, v, p, T are not
                          quantised); requires c_out <= 16 and no c_out_split */
+  int32_t sym_v;      /* number of y-mirrored filters (symmetry['v']) and of filters mirrored about both axes (symmetry['hv'],  */
+  int32_t sym_hv;     /* quadruples: x-, y- and xy-flips): output channels [U, c_out) in the reference's torch.cat order, */
+                      /* U = c_out - sym_h/2 - sym_v/2 - 3 sym_hv/4 unique filters (symmetric_layers_torch.py:118-136)   */
 } mc_conv_desc;
 
 typedef struct {

@@ -21,7 +21,7 @@ LOSS_TYPES = {"mae": 0, "mass": 1, "curl": 2}
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "c_in0", "c_in1", "c_out", "k", "pad", "pad_mode",
-                                          "dtype", "sym_h", "c_out_split", "out_f32")]
+                                          "dtype", "sym_h", "c_out_split", "out_f32", "sym_v", "sym_hv")]
 
 
 class GradSrc(C.Structure):

@@ -56,7 +56,7 @@ __global__ void k_pack_f32(ConvGeom g, const float* __restrict__ wu, int dgrad, 
 
 // ---- batched packing: the job table travels by value in the kernel arguments (<= PK_MAX jobs per launch)
 struct PkJob {
-  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP;
+  int K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, nh, nv, nq, CBout, CinP, CoutP;
   int dgrad, steps, ntiles, bf16, f16, rr, first_block;
   unsigned total;
   const float* w;
@@ -82,10 +82,10 @@ __global__ void k_pack_batched(PkTable t) {
   }
 }
 
-// dW_unique[u][ci][ky][kx] += sum_G part[G](tap, ci, u) + (u < h/2) sum_G part[G](x-mirrored tap, ci, U+u)
+// dW_unique[u][ci][ky][kx] += sum_G part[G](tap, ci, u) + the same sum over every mirrored copy of u at its mirrored tap
 // 64 outputs per block; the four waves split the slab range and combine through LDS (deterministic order)
 struct WfJob {
-  int K, U, Cin, Cin0, CB0, CinP, CoutP, Cout, symh, G, first_block;
+  int K, U, nh, nv, nq, Cin, Cin0, CB0, CinP, CoutP, Cout, G, first_block;
   const float* part;
   float* dw;
   float* db;
@@ -108,8 +108,9 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
   float s = 0.f;
   long dst = -1;                  // index into dw (>= 0), or -2 - co for the bias
   if (i < total) {
-    size_t o1, o2 = 0;
-    bool two = false, live = true;
+    size_t o1, ox[3] = {0, 0, 0};
+    int nx = 0;                      // mirrored copies of this unique filter (0, 1 or 3)
+    bool live = true;
     if (i < nW) {
       int cl = (int)(i & 15);
       size_t r = i >> 4;
@@ -121,7 +122,15 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
       live = cip < g.CB0 * 8 ? cip < g.Cin0 : ci < g.Cin;
       int ky = tap / K, kx = tap - ky * K;
       o1 = wg_index(tap, cip, u, g.CoutP, nch);
-      if (u < g.symh / 2) { two = true; o2 = wg_index(ky * K + (K - 1 - kx), cip, g.U + u, g.CoutP, nch); }
+      const int tfx = ky * K + (K - 1 - kx), tfy = (K - 1 - ky) * K + kx, tfxy = (K - 1 - ky) * K + (K - 1 - kx);
+      if (u < g.nh) { nx = 1; ox[0] = wg_index(tfx, cip, g.U + u, g.CoutP, nch); }
+      else if (u < g.nh + g.nv) { nx = 1; ox[0] = wg_index(tfy, cip, g.U + u, g.CoutP, nch); }
+      else if (u < g.nh + g.nv + g.nq) {
+        const int c0 = g.U + g.nh + g.nv + (u - g.nh - g.nv);
+        nx = 3;
+        ox[0] = wg_index(tfx, cip, c0, g.CoutP, nch); ox[1] = wg_index(tfy, cip, c0 + g.nq, g.CoutP, nch);
+        ox[2] = wg_index(tfxy, cip, c0 + 2 * g.nq, g.CoutP, nch);
+      }
       dst = ((long)u * g.Cin + ci) * KK + tap;
     } else {
       o1 = (size_t)KK * nch * g.CoutP * 16 + (i - nW);
@@ -134,14 +143,14 @@ __device__ __forceinline__ void wgrad_finalize_block(const WfJob& g, int lblock)
       for (; G + 3 * NWV < g.G; G += 4 * NWV) {
         a0 += part[(size_t)G * slab + o1]; a1 += part[(size_t)(G + NWV) * slab + o1];
         a2 += part[(size_t)(G + 2 * NWV) * slab + o1]; a3 += part[(size_t)(G + 3 * NWV) * slab + o1];
-        if (two) {
-          a0 += part[(size_t)G * slab + o2]; a1 += part[(size_t)(G + NWV) * slab + o2];
-          a2 += part[(size_t)(G + 2 * NWV) * slab + o2]; a3 += part[(size_t)(G + 3 * NWV) * slab + o2];
+        for (int m = 0; m < nx; ++m) {
+          a0 += part[(size_t)G * slab + ox[m]]; a1 += part[(size_t)(G + NWV) * slab + ox[m]];
+          a2 += part[(size_t)(G + 2 * NWV) * slab + ox[m]]; a3 += part[(size_t)(G + 3 * NWV) * slab + ox[m]];
         }
       }
       for (; G < g.G; G += NWV) {
         a0 += part[(size_t)G * slab + o1];
-        if (two) a0 += part[(size_t)G * slab + o2];
+        for (int m = 0; m < nx; ++m) a0 += part[(size_t)G * slab + ox[m]];
       }
       s = (a0 + a1) + (a2 + a3);
     } else {
@@ -171,7 +180,7 @@ int wf_fill(const mc_conv_desc* d, const void* partials, float* dw, float* db, W
   if (rc) return rc;
   if (!partials || (!dw && !db)) return MC_EINVAL;
   j.K = g.K; j.U = g.U; j.Cin = g.Cin; j.Cin0 = g.Cin0; j.CB0 = g.CB0; j.CinP = g.CinP; j.CoutP = g.CoutP; j.Cout = g.Cout;
-  j.symh = g.sym_h; j.G = g.wgrad_G; j.part = (const float*)partials; j.dw = dw; j.db = db;
+  j.nh = g.nh; j.nv = g.nv; j.nq = g.nq; j.G = g.wgrad_G; j.part = (const float*)partials; j.dw = dw; j.db = db;
   size_t total = (size_t)g.K * g.K * wg_chunks(g.CinP) * g.U * 16 + g.Cout;
   blocks = (int)((total + 63) / 64);
   return MC_OK;
@@ -387,6 +396,7 @@ int mc_pack_weights_batched(const mc_conv_desc* descs, const float* const* w_uni
       if (!w_unique[base + k] || !packed[base + k]) return MC_EINVAL;
       PkJob& j = t.j[k];
       j.K = g.K; j.Cout = g.Cout; j.CBin = g.CBin; j.CB0 = g.CB0; j.Cin0 = g.Cin0; j.Cin1 = g.Cin1; j.Cin = g.Cin; j.U = g.U;
+      j.nh = g.nh; j.nv = g.nv; j.nq = g.nq;
       j.CBout = g.CBout; j.CinP = g.CinP; j.CoutP = g.CoutP; j.dgrad = dgrad[base + k]; j.bf16 = mc_is16(g.dtype);
       j.f16 = (g.dtype == MC_MIX16 && !j.dgrad) ? 1 : 0;       // forward banks of MC_MIX16 are f16, input-gradient banks bf16
       j.rr = bank_is_rr(g, j.dgrad);

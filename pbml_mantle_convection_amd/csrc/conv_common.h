@@ -11,7 +11,8 @@ struct ConvGeom {
   int split8;               // dgrad: first split8 output blocks go to y0 (0 = no split)
   int tiles_x, tiles_y, tiles;
   int wgrad_G;              // number of partial slabs of the filter-gradient reduction
-  int sym_h, U;             // mirrored filters / unique filters
+  int sym_h, U;             // x-mirrored filters / unique filters
+  int nh, nv, nq;           // pairs mirrored in x, in y, quadruples mirrored about both axes (symmetry h/2, v/2, hv/4)
   int dtype;
   int out_f32;
 };
@@ -68,7 +69,9 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   if (d->pad_mode < MC_PAD_ZEROS || d->pad_mode > MC_PAD_REFLECT) return MC_EINVAL;
   if (d->pad_mode == MC_PAD_REFLECT && (d->pad >= d->h || d->pad >= d->w)) return MC_EINVAL;
   if (d->c_in1 > 0 && (d->c_in0 % 8) != 0) return MC_EUNSUPPORTED;
-  if (d->sym_h < 0 || (d->sym_h & 1) || d->sym_h > d->c_out) return MC_EINVAL;
+  if (d->sym_h < 0 || (d->sym_h & 1) || d->sym_v < 0 || (d->sym_v & 1) || d->sym_hv < 0 || (d->sym_hv & 3) ||
+      d->sym_h + d->sym_v + d->sym_hv > d->c_out)
+    return MC_EINVAL;
   if (d->c_out_split != 0 && (d->c_out_split < 0 || d->c_out_split >= d->c_out || (d->c_out_split % 8) != 0))
     return MC_EINVAL;
   g.N = d->n; g.H = d->h; g.W = d->w; g.K = d->k; g.pad = d->pad; g.pad_mode = d->pad_mode;
@@ -82,7 +85,8 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
   g.tiles_x = (g.Wo + tile_w - 1) / tile_w;
   g.tiles_y = (g.Ho + tile_h - 1) / tile_h;
   g.tiles = g.tiles_x * g.tiles_y;
-  g.sym_h = d->sym_h; g.U = d->c_out - d->sym_h / 2;
+  g.sym_h = d->sym_h; g.nh = d->sym_h / 2; g.nv = d->sym_v / 2; g.nq = d->sym_hv / 4;
+  g.U = d->c_out - g.nh - g.nv - 3 * g.nq;
   g.dtype = d->dtype;
   g.out_f32 = mc_is16(d->dtype) ? d->out_f32 : 0;
   if (g.out_f32 < 0 || g.out_f32 > 1) return MC_EINVAL;
@@ -120,7 +124,22 @@ static __host__ __device__ inline int cin_padded_index(int ci, int Cin0, int CB0
 
 // ------------------------------------------------------------------------------------------------
 // filter-bank element generators shared by the single-layer and the batched pack kernels.
-// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, CBout, CinP, CoutP.
+// G is any struct with the fields K, Cout, CBin, CB0, Cin0, Cin1, Cin, U, nh, nv, nq, CBout, CinP, CoutP.
+// Output channel co >= U is a mirrored copy of a unique filter (the reference's torch.cat order: x-flips of unique [0, nh),
+// y-flips of [nh, nh + nv), then the x-, y- and xy-flips of [nh + nv, nh + nv + nq); symmetric_layers_torch.py:118-136).
+template <typename G>
+__host__ __device__ __forceinline__ int mirror_source(const G& g, int co, bool& fx, bool& fy) {
+  fx = fy = false;
+  if (co < g.U) return co;
+  int j = co - g.U;
+  if (j < g.nh) { fx = true; return j; }
+  j -= g.nh;
+  if (j < g.nv) { fy = true; return g.nh + j; }
+  j -= g.nv;
+  const int blk = g.nq > 0 ? j / g.nq : 0;
+  fx = blk == 0 || blk == 2; fy = blk == 1 || blk == 2;
+  return g.nh + g.nv + (g.nq > 0 ? j % g.nq : 0);
+}
 // ------------------------------------------------------------------------------------------------
 template <typename G>
 __device__ __forceinline__ float bank_source(const G& g, const float* __restrict__ wu, int co, int cip, int ky, int kx) {
@@ -130,9 +149,10 @@ __device__ __forceinline__ float bank_source(const G& g, const float* __restrict
   if (!ok) return 0.f;
   int ci = ob < g.CB0 ? ob * 8 + oj : g.Cin0 + (ob - g.CB0) * 8 + oj;
   const int cw = g.Cin;
-  int u = co, kxs = kx;
-  if (co >= g.U) { u = co - g.U; kxs = g.K - 1 - kx; }        // x-mirrored copy (symmetric_layers_torch.py:121-123)
-  return wu[(((size_t)u * cw + ci) * g.K + ky) * g.K + kxs];
+  bool fx, fy;
+  const int u = mirror_source(g, co, fx, fy);
+  const int kxs = fx ? g.K - 1 - kx : kx, kys = fy ? g.K - 1 - ky : ky;
+  return wu[(((size_t)u * cw + ci) * g.K + kys) * g.K + kxs];
 }
 
 // f32 bank [cbin][tap][ci8][CoutP] (dgrad: [cb over C_out][tap][j][CinP], rotated taps)

@@ -51,6 +51,8 @@ class ConvNode:
     learned: bool = False      # BoundaryLearnedConvolution2D ("learned padding"): nine valid banks + one shared bias,
     bc_x: int = 1              # name + {conv, conv_top_left, ...}.weight / name + learnable_bias; bc > 1 widens the
     bc_y: int = 1              # border strips so that the output grows (Unet's first layer, reference :1995)
+    sym_v: int = 0             # y-mirrored filters / filters mirrored about both axes (SymmetricConv2d symmetry 'v' / 'hv';
+    sym_hv: int = 0            # FluidLayer never sets them, reference :755-757)
 
 
 @dataclass
@@ -291,11 +293,12 @@ def newfluidnet_graph(levels, c_i, c_h, c_o, *, act, r_p, use_symm, repeats, f, 
     return NetGraph(c_i, c_o, ch, nodes, subtract_mean=True, pad_mode="zeros" if learned else r_p, act=act, divisor=1)
 
 
-def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool, learned: bool = False) -> NetGraph:
+def single_layer_graph(c_in, c_out, k, pad, pad_mode, sym_h, post, act, groups, gn: bool, learned: bool = False,
+                       sym_v: int = 0, sym_hv: int = 0) -> NetGraph:
     """One conv (+GN+act): SymmetricConv2d / FluidLayer used stand-alone."""
     ch = {0: c_in, 1: c_out}
     node = ConvNode("layers.0." if gn else "", [0], 1, c_out, k, pad, sym_h, post, "layers.1." if gn else None, groups,
-                    learned=learned)
+                    learned=learned, sym_v=sym_v, sym_hv=sym_hv)
     return NetGraph(c_in, c_out, ch, [node], pad_mode=pad_mode, act=act)
 
 
@@ -339,7 +342,7 @@ def iter_conv_descs(g: NetGraph, N: int, H: int, W: int, precision: str):
             ho, wo = h + 2 * node.pad - k + 1, w + 2 * node.pad - k + 1
             final_f32 = node.post == L.POST_NONE and node is g.nodes[-1] and mc != L.MC_F32 and node.c_out <= 16
             d = L.ConvDesc(N, h, w, cs[0], cs[1] if len(cs) > 1 else 0, node.c_out, k, node.pad, mode, mc, node.sym_h, 0,
-                           int(final_f32))
+                           int(final_f32), node.sym_v, node.sym_hv)
             dd = None
             if any(grad[i] for i in node.srcs):
                 dd = L.ConvDesc(N, ho, wo, node.c_out, 0, sum(cs), k, k - 1, 0, mcg, 0, cs[0] if len(cs) > 1 else 0, 0)
@@ -536,7 +539,7 @@ class Engine:
             ho, wo = h + 2 * node.pad - node.k + 1, w + 2 * node.pad - node.k + 1
             omode = int(final_f32)
             d = L.ConvDesc(N, h, w, srcs[0].C, srcs[1].C if len(srcs) > 1 else 0, node.c_out, node.k, node.pad,
-                           mode, self.mc_dtype, node.sym_h, 0, omode)
+                           mode, self.mc_dtype, node.sym_h, 0, omode, node.sym_v, node.sym_hv)
             o = T[node.out]
             o.H, o.W = ho, wo
             tiles = L.call("mc_conv_tiles", C.byref(d))

@@ -50,7 +50,7 @@ class HipNetMixin:
 
     def _init_hipnet(self, graph: NetGraph, precision: str = None):
         self._graph = graph
-        self._precision = precision or DEFAULT_PRECISION
+        self._precision = precision or getattr(self, "_precision", None) or DEFAULT_PRECISION   # (keeps an earlier set_precision)
         self._engines: Dict[str, Engine] = {}
         self._fwd_version = 0
         self._pnames: List[str] = []

@@ -3,8 +3,9 @@ layer (reference symmetric_layers_torch.py:21-138), forward/backward on the HIP 
 
 The reference rebuilds the full filter bank every forward with torch.flip + torch.cat and
 hands it to ATen's conv2d; here the mirrored copies are never materialised in the reference
-layout: the bank packer reads filter j >= U as filter j-U with kx reversed, and the filter
-gradient folds dW_full[U+i] (x-flipped) back onto dW_unique[i].
+layout: the bank packer reads filter j >= U as its unique source with kx and / or ky reversed
+('h' pairs, 'v' pairs, 'hv' quadruples in the reference's torch.cat order), and the filter
+gradient folds every mirrored copy's dW (flipped back) onto the unique filter's.
 """
 import math
 
@@ -71,12 +72,9 @@ class SymmetricConv2d(nn.Conv2d, HipNetMixin):
         if self.bias is None:
             raise NotImplementedError("HIP SymmetricConv2d expects bias=True (as every reference call site)")
         s = self.symmetry or {"h": 0, "v": 0, "hv": 0}
-        if s["v"] or s["hv"]:
-            raise NotImplementedError("only 'h' mirrored filters are implemented (the only kind FluidLayer uses, "
-                                      "reference pytorch_networks_convae.py:755-757)")
         pad = _same_padding(self.kernel_size, self.padding, self.dilation)
         self._init_hipnet(single_layer_graph(self.in_channels, self.out_channels, k, pad, self.padding_mode, s["h"],
-                                             L.POST_NONE, "none", 1, gn=False))
+                                             L.POST_NONE, "none", 1, gn=False, sym_v=s["v"], sym_hv=s["hv"]))
         self._graph_built = True
 
     def forward(self, input):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     import ctypes as C
     from pbml_mantle_convection_amd import _lib
-    assert C.sizeof(_lib.ConvDesc) == 13 * 4
+    assert C.sizeof(_lib.ConvDesc) == 15 * 4
     assert C.sizeof(_lib.GradSrc) == 8 + 8 * 4
     assert C.sizeof(_lib.LossDesc) == 12 * 4
 
