@@ -605,6 +605,36 @@ def build_unet_input(gVTp: Tensor, roll_forward: int = 1) -> Tensor:
     return x
 
 
+def unet_roll_forward(forward, gVTp: Tensor, paras: Tensor, roll_forward: int):
+    """multigpu.py:207-248 for roll_forward = R > 1: the network is applied R * R times in a chain -- per outer round R - 1
+    pre-steps under no_grad and one more step; only the LAST evaluation is differentiated (every earlier output enters the
+    next input through a no_grad step or is overwritten).  Each input is rebuilt from the ORIGINAL xc, yc, dt and parameter
+    channels and the previous evaluation's (T, u, v); the viscosity channel is re-derived from T after the PRE-steps only
+    (the recomputation after a round's last step is commented out in the reference, :247: the next round starts with the V of
+    the previous pre-step): V = log10(clip(exp(-ln(fkt) T + ln(fkp) (1 - yc)), 1e-8, 1)) / 8 (yc: the unscaled channel 1 of
+    gVTp; paras = (raq, fkt, fkp)).  `forward(x)` -> (u, v, p, T) of the 10-channel input x.  Returns the last outputs."""
+    R_ = int(roll_forward)
+    x = build_unet_input(gVTp, R_)
+    yc = gVTp[:, 1:2]
+    fkt, fkp = paras.reshape(-1, 3)[:, 1].view(-1, 1, 1, 1), paras.reshape(-1, 3)[:, 2].view(-1, 1, 1, 1)
+    B, _, H, W = gVTp.shape
+    out = None
+    for i in range(R_ * R_):
+        last = i == R_ * R_ - 1
+        with torch.set_grad_enabled(last):
+            out = forward(x)
+        if last:
+            break
+        u, v, p, T = out
+        T = T.detach().reshape(B, 1, H, W)
+        x = x.clone()
+        if i % R_ != R_ - 1:                                 # a pre-step: the viscosity channel follows its T
+            x[:, 6:7] = torch.log10(torch.clip(torch.exp(torch.log(fkt) * (0.0 - T) + torch.log(fkp) * (1.0 - yc)), 1e-8, 1.0)) / 8.0
+        x[:, 7:8] = T
+        x[:, 8:9], x[:, 9:10] = u.detach().reshape(B, 1, H, W), v.detach().reshape(B, 1, H, W)
+    return out
+
+
 def divergence_abs(u: Tensor, v: Tensor) -> Tensor:
     """|du/dx + dv/dy| on the (H-2)x(W-2) interior, [B,1,H-2,W-2] (multigpu.py:274-286)."""
     H, W = u.shape[-2:]

@@ -298,6 +298,27 @@ def test_two_training_steps(golden, tag):
         close(p_, g["sd2/" + k_], rtol=1e-7, atol=1e-9)
 
 
+def test_get_loss_roll_forward_2(golden):
+    """get_loss with roll_forward = 2 (multigpu.py:207-248): the oracle's restatement of the R x R chain of network
+    evaluations (only the last one differentiated) against the reference's losses and parameter gradients."""
+    g = golden("g21_get_loss_roll2")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm, ls, ld, R = [int(v) for v in g["cfg"]]
+    B, H, W = 1, 128, 506
+    sd = {k[4:]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd0/")}
+    gVTp = T(fields.unet_input(B, H, W, 2100, c_i=11))
+    truth = [fields.smooth_field(B, H, W, 2150), fields.smooth_field(B, H, W, 2160), fields.smooth_field(B, H, W, 2170, amp=0.5),
+             fields.temperature_field(B, H, W, 2180)]
+    uvp = T(np.stack(truth, 1))
+    fwd = lambda x: O.unet_forward(sd, x, levels=levels, repeats=repeats, act="gelu", r_p="reflect", loss_type="mass",  # noqa: E731
+                                   use_symm=bool(symm), p_pred=bool(p_pred))
+    pred = O.unet_roll_forward(fwd, gVTp, T(g["paras"]), R)
+    out = O.get_loss_unet(pred, uvp, p_pred=bool(p_pred), loss_type="mass")
+    close(np.array([float(o.detach()) for o in out[:6]]), g["losses"], rtol=1e-8)
+    out[0].backward()
+    for k_, p_ in sd.items():
+        close(p_.grad, g["grad0/" + k_], atol=1e-10, rtol=1e-7)
+
+
 def test_momentum_residual_constant_viscosity_identity():
     """Build-defined term: with eta == 1 and p == 0 the flux form must reduce to
     126^2 (laplace(U) + d2U/dx2 + d2V/dxdy), built from the reference's own FD kernels."""

@@ -373,6 +373,35 @@ def g11():
             loss_type=np.array(loss_type), **sd0, **g0, **sd2)
 
 
+# ------------------------------------------------------------------ G21 get_loss with roll_forward = 2 (multigpu.py:207-248)
+def g21():
+    """The reference's get_loss with roll_forward = 2 on a tiny Unet at its native 128 x 506 grid (the views are hard-coded),
+    fp64: the six losses and every parameter gradient."""
+    B, H, W, R = 1, 128, 506, 2
+    m = P.Unet(3, 10, 8, 4, CPU, "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True).double()
+    randomize_(m, 210)
+    sd0 = {("sd0/" + k): v.clone().float() for k, v in m.state_dict().items()}
+    ns = _trainer_ns(m, True, False, False, "mass")
+    ns.roll_forward = R
+    gVTp = torch.from_numpy(fields.unet_input(B, H, W, 2100, c_i=11))
+    truth = [fields.smooth_field(B, H, W, 2150), fields.smooth_field(B, H, W, 2160), fields.smooth_field(B, H, W, 2170, amp=0.5),
+             fields.temperature_field(B, H, W, 2180)]
+    uvp = torch.from_numpy(np.stack(truth, 1))
+    paras = torch.tensor([[5.0, 1.0e7, 10.0]], dtype=f64).view(B, 3, 1, 1)
+    inner = m
+
+    class Sq(torch.nn.Module):
+        def forward(self, x):
+            u, v, p, T = inner(x)
+            return u[:, 0], v[:, 0], p[:, 0], T[:, 0]
+    ns.model_uvp = Sq()
+    out = G.Trainer.get_loss(ns, gVTp, uvp, None, paras, gVTp[:, 1:2])
+    out[0].backward()
+    g0 = {("grad0/" + k): p.grad.clone() for k, p in m.named_parameters()}
+    npz("g21_get_loss_roll2", losses=np.array([float(o) for o in out]), paras=paras.view(B, 3),
+        cfg=np.array([3, 10, 8, 4, 2, 5, 1, 1, 0, 0, R]), **sd0, **g0)
+
+
 # ------------------------------------------------------------------ G12 NewFluidNet (SURVEY 8f N1)
 def g12():
     for tag, (loss_type, r_p, symm, act, c_i) in {
@@ -697,6 +726,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21):
         if not only or fn.__name__ in only:
             fn()
