@@ -378,6 +378,15 @@ int mc_assemble_newad_batch(const float* T, const float* uvp, const float* t, co
                             const float* xc, const float* yc, const int32_t* idx, int32_t b, int32_t m, int32_t cy,
                             int32_t h, int32_t w, float* x, float* y, float* t_weight, float* scaler, void* stream);
 
+/* ---- Trainer.get_loss with roll_forward = R > 1 (multigpu.py:207-248): the network is applied R * R times in a chain, each
+ * input rebuilt from channels 0..5 of the batch and the previous evaluation's T, u, v.  x [n][c][h][w] f32 (c >= 10) holds the
+ * batch's RAW channels (the input-pack kernel applies xc / 4, yc / 4, dt / R); this call overwrites channels 7, 8, 9 with t, u,
+ * v ([h][w] planes with a batch stride: the curl head's outputs or channels of the network output) and, when update_v != 0
+ * (after a pre-step; the reference leaves V alone after a round's last step, :246-247), channel 6 with
+ * log10(clip(exp(-ln(FKT) t + ln(FKP) (1 - yc)), 1e-8, 1)) / 8, yc = channel 1 of x; paras [n][3] = (RaQ, FKT, FKP). */
+int mc_roll_forward_update(float* x, int32_t c, const float* u, const float* v, const float* t, int64_t uvt_batch_stride,
+                           const float* paras, int32_t update_v, int32_t n, int32_t h, int32_t w, void* stream);
+
 /* ---- inference rollout (TS.forward / ADNet.forward, pytorch_networks_convae.py:266-568) ----------
  * Input builder of the 'newfluidnet' branch (:372-395): out [n][7][h][w] = (xc/4, yc/4, log10(clip(eta,1e-8,1))/8, nd0, nd1,
  * nd2, T) with eta = exp(-ln(FKT) T + ln(FKP) (1 - ycc)); T [n][h][w], xc/yc/ycc [h][w], paras [n][3] = (RaQ, FKT, FKP),

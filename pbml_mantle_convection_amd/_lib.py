@@ -115,6 +115,7 @@ SIGNATURES = {
     "mc_assemble_newad_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mc_ts_build_input": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "mc_ts_build_input_unet": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "mc_roll_forward_update": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mc_ts_wall_bc": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "mc_adnet_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp,
                                 _vp]),

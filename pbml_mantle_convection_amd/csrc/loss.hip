@@ -418,6 +418,27 @@ __global__ void k_ts_build_input_unet(const float* __restrict__ T, const float* 
     o[9 * (size_t)HW + i] = vp[(size_t)n * HW + i];
   }
 }
+// Trainer.get_loss with roll_forward > 1 (multigpu.py:207-248): the next input keeps channels 0..5 of the batch and takes
+// T, u, v from the evaluation just done; the viscosity channel follows T after a pre-step only (update_v), with the depth of the
+// UNSCALED yc channel (x holds the batch's raw channels; the input-pack kernel applies xc / 4, yc / 4, dt / R)
+__global__ void k_roll_forward_update(float* __restrict__ x, int C, const float* __restrict__ u, const float* __restrict__ v,
+                                      const float* __restrict__ T, size_t uvt_stride, const float* __restrict__ paras,
+                                      int update_v, int HW) {
+  const int n = blockIdx.y;
+  const float lnfkt = logf(paras[n * 3 + 1]), lnfkp = logf(paras[n * 3 + 2]);
+  float* o = x + (size_t)n * C * HW;
+  const float *un = u + n * uvt_stride, *vn = v + n * uvt_stride, *Tn = T + n * uvt_stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const float t = Tn[i];
+    if (update_v) {
+      const float eta = fminf(fmaxf(expf(-lnfkt * t + lnfkp * (1.0f - o[HW + i])), 1e-8f), 1.0f);
+      o[6 * (size_t)HW + i] = log10f(eta) * 0.125f;
+    }
+    o[7 * (size_t)HW + i] = t;
+    o[8 * (size_t)HW + i] = un[i];
+    o[9 * (size_t)HW + i] = vn[i];
+  }
+}
 // T[:, 0, :] = 1, T[:, -1, :] = 0, then the side columns copy their inner neighbours (:441-444); one block per sample
 __global__ void k_ts_wall_bc(const float* __restrict__ src, int H, int W, float* __restrict__ dst) {
   const float* s = src + (size_t)blockIdx.x * H * W;
@@ -693,6 +714,16 @@ int mc_ts_build_input_unet(const float* T, const float* xc, const float* yc, con
   dim3 grid(max(1, min(cdiv(h * w, 256), 1024)), n);
   hipLaunchKernelGGL(k_ts_build_input_unet, grid, dim3(256), 0, (hipStream_t)stream, T, xc, yc, ycc, paras, paras_nd, dt, u_prev,
                      v_prev, h * w, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_roll_forward_update(float* x, int32_t c, const float* u, const float* v, const float* t, int64_t uvt_batch_stride,
+                           const float* paras, int32_t update_v, int32_t n, int32_t h, int32_t w, void* stream) {
+  if (!x || !u || !v || !t || !paras || c < 10 || n <= 0 || h <= 0 || w <= 0 || uvt_batch_stride < (int64_t)h * w) return MC_EINVAL;
+  dim3 grid(max(1, min(cdiv(h * w, 256), 1024)), n);
+  hipLaunchKernelGGL(k_roll_forward_update, grid, dim3(256), 0, (hipStream_t)stream, x, c, u, v, t, (size_t)uvt_batch_stride, paras,
+                     update_v, h * w);
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

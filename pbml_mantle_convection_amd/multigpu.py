@@ -102,8 +102,6 @@ class Trainer:
             raise NotImplementedError("the momentum residual needs the temperature output of the Unet")
         if model_AD is not None:
             raise NotImplementedError("model_AD (advection net) is out of scope of the training hot path")
-        if roll_forward != 1:
-            raise NotImplementedError("roll_forward > 1 (autoregressive pre-steps) is not implemented")
         self.gpu_id = gpu_id
         self.device = torch.device("cuda", gpu_id) if isinstance(gpu_id, int) else torch.device(gpu_id)
         self.train_data, self.cv_data = train_data, cv_data
@@ -181,11 +179,53 @@ class Trainer:
         m._chan_scale = self.chan_scale
         return m.features(gVTp)
 
+    def _rolls(self):
+        return self.roll_forward > 1 and self.net in ("unet", "iunet")      # the reference's other branches ignore it (:138)
+
+    def _roll_chain(self, gVTp, paras, fwd):
+        """roll_forward = R > 1 (reference :207-248): R * R network evaluations in a chain, per round R - 1 pre-steps under
+        no_grad and one more; every input is rebuilt from channels 0..5 of the batch and the previous evaluation's (T, u, v),
+        with the viscosity channel re-derived from T after the pre-steps only (:246-247 are commented out).  Only the LAST
+        evaluation reaches the loss with a gradient path (every earlier output enters the next input through a no_grad
+        step), so the first R * R - 1 run forward-only here; returns the last evaluation's input (raw channels: the
+        input-pack kernel scales xc, yc, dt).  `fwd(x)` -> network output [N, c_out, H, W] f32."""
+        if paras is None:
+            raise ValueError("roll_forward > 1 needs paras (RaQ, FKT, FKP per sample) for the viscosity channel")
+        R = int(self.roll_forward)
+        N, C, H, W = gVTp.shape
+        if C < 10:
+            raise ValueError(f"roll_forward > 1 rebuilds a 10-channel input; gVTp has {C} channels")
+        key = (N, C, H, W, str(gVTp.device))
+        if getattr(self, "_roll_key", None) != key:              # (a captured step allocates these in its warm-up pass)
+            self._roll_x = torch.empty((N, C, H, W), dtype=torch.float32, device=gVTp.device)
+            self._roll_uvT = torch.empty((3, N, H, W), dtype=torch.float32, device=gVTp.device)
+            self._roll_key = key
+        x = self._roll_x
+        x.copy_(gVTp)
+        p3 = paras.to(torch.float32).reshape(N, 3).contiguous()
+        m = self.model_uvp
+        for i in range(R * R - 1):
+            y = fwd(x)
+            Cc = y.shape[1]
+            if m.loss_type == "curl":                            # Unet.forward's head (u, v from the streamfunction; T clipped)
+                u, v, T = self._roll_uvT[0], self._roll_uvT[1], self._roll_uvT[2]
+                L.call("mc_curl_head_fwd", L.ptr(y), y.data_ptr() + 4 * H * W, N, H, W, Cc * H * W, float(m.a_bound), 0.0, 1.5,
+                       L.ptr(u), L.ptr(v), L.ptr(T), L.stream())
+                pu, pv, pT, stride = L.ptr(u), L.ptr(v), L.ptr(T), H * W
+            else:
+                pu, pv, pT, stride = y.data_ptr(), y.data_ptr() + 4 * H * W, y.data_ptr() + 8 * H * W, Cc * H * W
+            L.call("mc_roll_forward_update", L.ptr(x), C, pu, pv, pT, stride, L.ptr(p3), int(i % R != R - 1), N, H, W,
+                   L.stream())
+        return x
+
     def get_loss(self, gVTp, uvp, scaler, paras=None, yc=None):
         """Autograd-visible 6-tuple (loss, loss_true_u, loss_true_v, loss_p, loss_T, mean mass) exactly as the
         reference combines them (:250-305); `loss.backward()` runs the HIP backward."""
         gVTp = gVTp.to(self.device, torch.float32)
         uvp = uvp.to(self.device, torch.float32).contiguous()
+        if self._rolls():
+            with torch.no_grad():
+                gVTp = self._roll_chain(gVTp.contiguous(), None if paras is None else paras.to(self.device), self._features)
         y = self._features(gVTp)
         sc = None
         if self.loss.lambda_mom != 0.0:
@@ -221,7 +261,10 @@ class Trainer:
             eng.configure(gVTp.shape[0], gVTp.shape[2], gVTp.shape[3], gVTp.device)
             self._ybuf = torch.empty((gVTp.shape[0], eng.g.c_out, eng.out_h, eng.out_w), dtype=torch.float32, device=gVTp.device)
             self._ybuf_key = key
-        y = eng.forward(gVTp, params, self.chan_scale, out=self._ybuf if eng is m.engine() else None)
+        ybuf = self._ybuf if eng is m.engine() else None
+        if self._rolls():
+            gVTp = self._roll_chain(gVTp, paras, lambda x: eng.forward(x, params, self.chan_scale, out=ybuf))
+        y = eng.forward(gVTp, params, self.chan_scale, out=ybuf)
         out8, gy = loss.evaluate(y, uvp, yc, paras, scaler)
         if train:
             self.flat.grad.zero_()
@@ -333,7 +376,7 @@ class Trainer:
         uvp = uvp.to(self.device, torch.float32, non_blocking=True).contiguous()
         need = self.loss.lambda_mom != 0.0
         yc = yc.to(self.device, torch.float32) if (need and yc is not None) else None
-        paras = paras.to(self.device, torch.float32) if (need and paras is not None) else None
+        paras = paras.to(self.device, torch.float32) if ((need or self._rolls()) and paras is not None) else None
         scaler = scaler.to(self.device, torch.float32) if (need and scaler is not None) else None
         return gVTp, uvp, yc, paras, scaler
 

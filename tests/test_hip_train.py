@@ -205,6 +205,95 @@ def test_get_loss_autograd_path(golden):
         close(p.grad, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
 
 
+@pytest.mark.parametrize("path", ["fwd_bwd", "graph", "get_loss"])
+def test_roll_forward_2_golden(golden, path):
+    """Trainer with roll_forward = 2 (reference :207-248: 2 x 2 chained network evaluations, the viscosity channel re-derived
+    after the pre-steps) against the reference's own six losses and parameter gradients, on the raw-launch path, inside a
+    captured step and through the autograd-visible get_loss."""
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    g = golden("g21_get_loss_roll2")
+    levels, c_i, c_h, c_o, repeats, f, p_pred, symm, ls, ld, R = [int(v) for v in g["cfg"]]
+    B, H, W = 1, 128, 506
+    m = Unet(levels, c_i, c_h, c_o, torch.device(DEV), "gelu", "reflect", "mass", use_symm=bool(symm), repeats=repeats, f=f,
+             p_pred=bool(p_pred))
+    m.load_state_dict({k[4:]: torch.from_numpy(g[k]).float() for k in g.files if k.startswith("sd0/")})
+    opt = torch.optim.Adam(m.parameters(), lr=0.0)                         # lr 0: the captured step leaves the weights alone
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=bool(p_pred), network="unet",
+                 loss_type="mass", roll_forward=R, precision="fp32", use_graph=path == "graph")
+    gVTp = dev(fields.unet_input(B, H, W, 2100, c_i=11))
+    truth = [fields.smooth_field(B, H, W, 2150), fields.smooth_field(B, H, W, 2160), fields.smooth_field(B, H, W, 2170, amp=0.5),
+             fields.temperature_field(B, H, W, 2180)]
+    uvp, paras = dev(np.stack(truth, 1)), dev(g["paras"]).view(B, 3, 1, 1)
+    g_in = gVTp.clone()
+    if path == "get_loss":
+        for p_ in m.parameters():
+            p_.grad = None
+        loss6 = tr.get_loss(gVTp, uvp, None, paras, gVTp[:, 1:2])
+        loss6[0].backward()
+        vals = torch.stack([v.detach() for v in loss6])
+        grads = {n: p_.grad for n, p_ in m.named_parameters()}
+    else:
+        runs = 2 if path == "graph" else 1                                # the second call replays the captured chain
+        for _ in range(runs):
+            out8 = tr.train_step(gVTp, uvp, None, paras, None) if path == "graph" else tr._fwd_bwd(gVTp, uvp, None, paras, None)
+        vals = out8[:6]
+        grads = tr.flat.views(tr.flat.grad)
+    assert torch.equal(gVTp, g_in), "the batch itself must not be written"
+    close(vals, g["losses"], atol=1e-6, rtol=1e-4, what="losses")
+    for n, gr in grads.items():
+        ref = g["grad0/" + n]
+        close(gr, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what="grad " + n)
+
+
+@pytest.mark.parametrize("loss_type,R", [("curl", 2), ("curl", 3), ("mae", 3)])
+def test_roll_forward_matches_oracle(loss_type, R):
+    """R x R chain with the curl head between the evaluations (u, v from the streamfunction, T clipped) and R = 3 (two
+    pre-steps per round), two samples with different (FKT, FKP): losses and gradients against the oracle's chain."""
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    B, H, W = 2, 40, 72
+    torch.manual_seed(17)
+    m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", loss_type, use_symm=True, repeats=2, f=5, p_pred=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet", loss_type=loss_type,
+                 roll_forward=R, precision="fp32")
+    gVTp = fields.unet_input(B, H, W, 2300, c_i=11)
+    truth = [fields.smooth_field(B, H, W, 2350), fields.smooth_field(B, H, W, 2360), fields.smooth_field(B, H, W, 2370, amp=0.5),
+             fields.temperature_field(B, H, W, 2380)]
+    uvp = np.stack(truth, 1)
+    paras = np.array([[5.0, 1.0e7, 10.0], [3.0, 1.0e3, 100.0]])
+    out8 = tr._fwd_bwd(dev(gVTp), dev(uvp), None, dev(paras), None)
+    sd = {k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+    fwd = lambda x: O.unet_forward(sd, x, levels=3, repeats=2, act="gelu", r_p="reflect", loss_type=loss_type,  # noqa: E731
+                                   use_symm=True, p_pred=True)
+    pred = O.unet_roll_forward(fwd, torch.from_numpy(gVTp).to(f64), torch.from_numpy(paras).to(f64), R)
+    ref = O.get_loss_unet(pred, torch.from_numpy(uvp).to(f64), p_pred=True, loss_type=loss_type)
+    close(out8[:6], np.array([float(o.detach()) for o in ref[:6]]), atol=1e-6, rtol=2e-4, what="losses")
+    ref[0].backward()
+    for n, gr in tr.flat.views(tr.flat.grad).items():
+        r_ = sd[n].grad
+        if float(r_.abs().max()) < 1e-9:          # null direction (last bias: cancelled by the spatial mean subtraction)
+            continue
+        close(gr, r_, atol=1e-3 * max(1e-6, float(r_.abs().max())), rtol=5e-3, what="grad " + n)
+
+
+def test_roll_forward_needs_paras():
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.multigpu import Trainer
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+    tr = Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet", loss_type="mass",
+                 roll_forward=2, precision="fp32")
+    b = [t.to(DEV) for t in synthetic_batch(2, 48, 70, 11, p_pred=True, device="cpu")]
+    with pytest.raises(ValueError):
+        tr.train_step(b[0], b[1], None, None, None)
+
+
 def test_graph_step_in_place_input_buffers():
     """A batch written straight into the captured step's input buffers gives the same step as one passed by value."""
     from pbml_mantle_convection_amd.datasetio import synthetic_batch
