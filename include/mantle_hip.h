@@ -299,6 +299,13 @@ int mc_bicubic_bwd(const mc_grad_src* g, int32_t n, int32_t c, int32_t hi, int32
 int mc_bicubic_bwd_taps(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                         const int32_t* tys, const int32_t* tyj, const float* tyw, const int32_t* txs, const int32_t* txj,
                         const float* txw, int32_t max_taps_y, int32_t max_taps_x, int32_t dtype, void* dx, void* stream);
+/* The same adjoint as a walk down the output rows (each read once into registers; a sliding register window of the four
+ * open input rows; one LDS crossing per finished row for the x taps): takes the FORWARD y tables (idx_y, wgt_y: [ho][4], as
+ * mc_bicubic_fwd) plus the transposed lists (ty_start / ty_j for the chunk extents, the x lists for the gather).  Any ratio
+ * ho / hi >= 1; x tap lists of <= 12 entries (max_taps_x: the longest, host knowledge of the table), else MC_EUNSUPPORTED. */
+int mc_bicubic_bwd_walk(const mc_grad_src* gs, int32_t n, int32_t c, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                        const int32_t* idx_y, const float* wgt_y, const int32_t* tys, const int32_t* tyj, const int32_t* txs,
+                        const int32_t* txj, const float* txw, int32_t max_taps_x, int32_t dtype, void* dx, void* stream);
 /* The same adjoint as two 1-D passes through an f32 workspace [n][ceil(c/8)][hi][wo][8]: for large scale factors
  * (NewFluidNet upsamples x4 ... x16 to the full grid, pytorch_networks_convae.py:1239-1244), where a pixel's tap lists
  * are too long for the tiled kernel. */

@@ -103,6 +103,7 @@ SIGNATURES = {
     "mc_bicubic_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mc_bicubic_bwd": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                  _vp, _vp]),
+    "mc_bicubic_bwd_walk": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "mc_bicubic_bwd_taps": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _vp, _vp]),
     "mc_bicubic_bwd_separable": (C.c_int, [_GS, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,

@@ -357,6 +357,9 @@ def iter_conv_descs(g: NetGraph, N: int, H: int, W: int, precision: str):
 # ------------------------------------------------------------------------------------------------
 # bicubic tap tables (nn.Upsample(mode='bicubic', align_corners=False), A = -0.75), built in f64
 # ------------------------------------------------------------------------------------------------
+BICUBIC_WALK = os.environ.get("MANTLE_BICUBIC_WALK", "1") != "0"    # row-walk adjoint (mc_bicubic_bwd_walk) vs the tiled kernel
+
+
 def bicubic_tables(n_in: int, n_out: int):
     A = -0.75
     scale = n_in / n_out
@@ -930,8 +933,11 @@ class Engine:
             if node.kind == "up":
                 s, o = T[node.src], T[node.out]
                 assert len(o.gsrcs) == 1, "an upsampled tensor feeds exactly one conv"
-                (_, _, tys, tyj, tyw), (_, _, txs, txj, txw) = e["tabs"]
-                if "bws" in e:
+                (iy, wy, tys, tyj, tyw), (_, _, txs, txj, txw) = e["tabs"]
+                if "bws" not in e and e["maxtaps"][1] <= 12 and BICUBIC_WALK:
+                    L.call("mc_bicubic_bwd_walk", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(iy), L.ptr(wy), L.ptr(tys),
+                           L.ptr(tyj), L.ptr(txs), L.ptr(txj), L.ptr(txw), e["maxtaps"][1], self.mc_gdtype, L.ptr(e["dsrc"]), st)
+                elif "bws" in e:
                     L.call("mc_bicubic_bwd_separable", C.byref(o.gsrcs[0]), N, s.C, s.H, s.W, o.H, o.W, L.ptr(tys), L.ptr(tyj),
                            L.ptr(tyw), L.ptr(txs), L.ptr(txj), L.ptr(txw), self.mc_gdtype, L.ptr(e["bws"]), L.ptr(e["dsrc"]), st)
                 else:

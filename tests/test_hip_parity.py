@@ -132,6 +132,57 @@ def test_convae_golden(golden, tag):
         assert_close(p.grad, ref, atol=2e-4 * scale, rtol=1e-3, what=n)
 
 
+@pytest.mark.parametrize("kernel", ["walk", "taps"])
+@pytest.mark.parametrize("hi,wi,ho,wo,c,dt", [
+    (253, 256, 506, 512, 8, "bf16"),      # level 0 of the headline net: exact x2, one 512-column strip
+    (126, 128, 253, 256, 16, "bf16"),     # irregular ratio in y (the row window slips once), 12-entry y lists
+    (31, 32, 63, 64, 24, "f32"),          # 128-thread blocks, 3 channel blocks
+    (40, 300, 80, 600, 8, "f32"),         # wider than a block: column strips with their halo
+    (20, 24, 60, 72, 8, "f32"),           # x3: the window slides every third row
+    (30, 63, 60, 127, 8, "bf16"),         # irregular ratio in x (12-entry x lists)
+    (5, 6, 10, 12, 8, "f32"),             # every row and column clamped
+    (7, 9, 7, 9, 8, "f32"),               # identity-sized resample
+])
+def test_bicubic_adjoint_kernels_vs_torch(kernel, hi, wi, ho, wo, c, dt):
+    """The adjoint of nn.Upsample(mode='bicubic') -- the row-walk kernel (mc_bicubic_bwd_walk) and the tiled one
+    (mc_bicubic_bwd_taps) -- against torch's autograd of F.interpolate on the CPU (f64), from a plain gradient tensor and from
+    the interior of a padded one."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from pbml_mantle_convection_amd import _lib as L
+    from pbml_mantle_convection_amd.engine import bicubic_tables
+    L.load()
+    st = L.stream()
+    N = 2
+    gen = torch.Generator().manual_seed(hi * 1000 + wo)
+    gout = torch.randn((N, c, ho, wo), generator=gen)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    mcdt = L.MC_BF16 if dt == "bf16" else L.MC_F32
+    gq = gout.to(tdt).float()                                         # what the kernel reads
+    x = torch.zeros((N, c, hi, wi), dtype=torch.float64, requires_grad=True)
+    F.interpolate(x, size=(ho, wo), mode="bicubic", align_corners=False).backward(gq.double())
+    ref = x.grad.float()
+    ty, tx = bicubic_tables(hi, ho), bicubic_tables(wi, wo)
+    mt = [int(np.diff(t[2]).max()) for t in (ty, tx)]
+    dy, dxt = [torch.from_numpy(a).to(DEV) for a in ty], [torch.from_numpy(a).to(DEV) for a in tx]
+    c8 = c // 8
+    for pad in (0, 2):
+        full = torch.randn((N, c, ho + 2 * pad, wo + 2 * pad), generator=gen)          # halo: garbage that must not be read
+        full[:, :, pad:pad + ho, pad:pad + wo] = gq
+        buf = full.view(N, c8, 8, ho + 2 * pad, wo + 2 * pad).permute(0, 1, 3, 4, 2).contiguous().to(DEV).to(tdt)
+        gs = L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD if pad else L.GSRC_PLAIN, pad, 2, 1, ho, wo, 0, 0)
+        out = torch.full((N, c8, hi, wi, 8), float("nan"), device=DEV).to(tdt)
+        if kernel == "walk":
+            L.call("mc_bicubic_bwd_walk", C.byref(gs), N, c, hi, wi, ho, wo, L.ptr(dy[0]), L.ptr(dy[1]), L.ptr(dy[2]), L.ptr(dy[3]),
+                   L.ptr(dxt[2]), L.ptr(dxt[3]), L.ptr(dxt[4]), mt[1], mcdt, L.ptr(out), st)
+        else:
+            L.call("mc_bicubic_bwd_taps", C.byref(gs), N, c, hi, wi, ho, wo, L.ptr(dy[2]), L.ptr(dy[3]), L.ptr(dy[4]), L.ptr(dxt[2]),
+                   L.ptr(dxt[3]), L.ptr(dxt[4]), mt[0], mt[1], mcdt, L.ptr(out), st)
+        got = out.float().permute(0, 1, 4, 2, 3).reshape(N, c, hi, wi).cpu()
+        tol = 8e-3 if dt == "bf16" else 2e-5                              # bf16: the stored result's own rounding
+        torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+
+
 def test_concat_and_gradient_source_kinds():
     """mc_concat_cb8 (torch.cat of > 2 operands), mc_gsrc_sum, slices of a concatenated gradient and the AvgPool adjoint of a
     plain tensor (SURVEY 8f N1 plumbing) against torch."""
