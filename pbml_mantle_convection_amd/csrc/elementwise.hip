@@ -1106,6 +1106,110 @@ __global__ __launch_bounds__(256) void k_bicubic_fwd(const T* __restrict__ x, in
   }
 }
 
+// The upsample as a walk down the output rows (the forward twin of k_bicubic_bwd_walk below): thread = output column of a
+// strip, block = strip x chunk of output rows of one (sample, channel block).  An input row crosses LDS once (storage type,
+// activated on the way if asked), every thread interpolates it along x into registers (f32), and a register window of the
+// four x-interpolated rows under the current output row slides with the first tap; an output row is 4 x 8 FMAs and one
+// coalesced 16-byte store per thread.  Same summation order as the tiled kernel (x taps, then y taps) on unclamped rows.
+template <typename T, int SW>
+__global__ __launch_bounds__(SW) void k_bicubic_fwd_walk(const T* __restrict__ x, int C8, int Hi, int Wi, int Ho, int Wo,
+                                                         const int* __restrict__ iy, const float* __restrict__ wy,
+                                                         const int* __restrict__ ix, const float* __restrict__ wx,
+                                                         T* __restrict__ out, int rpc, int fw, int strips,
+                                                         const float* __restrict__ coef4, int act) {
+  constexpr int Q = sizeof(T) == 4 ? 2 : 1;
+  __shared__ uint4 crow[2][Q][SW];
+  const int n = blockIdx.z, cb = blockIdx.y, c = threadIdx.x;
+  const int strip = blockIdx.x % strips, chunk = blockIdx.x / strips;
+  const int r0 = chunk * rpc, r1 = min(Ho, r0 + rpc);
+  const int F0 = strip * fw, F1 = min(Wo, F0 + fw);
+  if (r0 >= r1 || F0 >= F1) return;                                     // (block-uniform)
+  const int C0 = ix[F0 * 4];                                            // clamped tables are non-decreasing
+  const int ncw = min(ix[(F1 - 1) * 4 + 3] - C0 + 1, SW);
+  const bool outok = F0 + c < F1;
+  const int xo = min(F0 + c, F1 - 1);
+  int jx[4];
+  float fx[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    jx[b] = min(max(ix[xo * 4 + b] - C0, 0), SW - 1);
+    fx[b] = wx[xo * 4 + b];
+  }
+  float sc[8], sh[8];
+  if (act >= 0) load_coef8(coef4, n, C8 * 8, cb, sc, sh);
+  const T* src = x + cb8_index(n, cb, 0, min(C0 + c, Wi - 1), C8, Hi, Wi);
+  const size_t rstride = (size_t)Wi * 8;
+  auto ldrow = [&](int yi, uint4 (&r)[Q]) {
+    if (c < ncw) {
+      const char* p = reinterpret_cast<const char*>(src + (size_t)min(yi, Hi - 1) * rstride);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) r[q] = *reinterpret_cast<const uint4*>(p + 16 * q);
+    }
+  };
+  float win[4][8];
+  int buf = 0;
+  // input row (registers) -> LDS -> this thread's x interpolation, into the top of the window
+  auto push = [&](uint4 (&r)[Q]) {
+    if (c < ncw) {
+      if (act >= 0) XformRaw<T>::apply(r, sc, sh, act);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) crow[buf][q][c] = r[q];
+    }
+    __syncthreads();                       // (one barrier per input row: the buffer written two rows on was read before the next one)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { win[0][j] = win[1][j]; win[1][j] = win[2][j]; win[2][j] = win[3][j]; win[3][j] = 0.f; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float v[8];
+      if constexpr (sizeof(T) == 4) {
+        const uint4 lo = crow[buf][0][jx[b]], hi = crow[buf][Q - 1][jx[b]];
+        v[0] = __uint_as_float(lo.x); v[1] = __uint_as_float(lo.y); v[2] = __uint_as_float(lo.z); v[3] = __uint_as_float(lo.w);
+        v[4] = __uint_as_float(hi.x); v[5] = __uint_as_float(hi.y); v[6] = __uint_as_float(hi.z); v[7] = __uint_as_float(hi.w);
+      } else {
+        V8<T>::ld(reinterpret_cast<const T*>(&crow[buf][0][jx[b]]), v);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) win[3][j] += fx[b] * v[j];
+    }
+    buf ^= 1;
+  };
+  int basey = __builtin_amdgcn_readfirstlane(iy[r0 * 4]);               // window = input rows basey .. basey + 3 (clamped)
+  uint4 nx[Q];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ldrow(basey + k, nx);
+    push(nx);
+  }
+  ldrow(basey + 4, nx);                                                  // the next row: in flight until the window slides
+  for (int yo = r0; yo < r1; ++yo) {
+    const int t0 = __builtin_amdgcn_readfirstlane(iy[yo * 4]), t1 = __builtin_amdgcn_readfirstlane(iy[yo * 4 + 1]),
+              t2 = __builtin_amdgcn_readfirstlane(iy[yo * 4 + 2]), t3 = __builtin_amdgcn_readfirstlane(iy[yo * 4 + 3]);
+    const float w0 = wy[yo * 4], w1 = wy[yo * 4 + 1], w2 = wy[yo * 4 + 2], w3 = wy[yo * 4 + 3];
+    while (basey < t0) {
+      push(nx);
+      ++basey;
+      ldrow(basey + 4, nx);
+    }
+    float o[8];
+    if (t1 == basey + 1 && t2 == basey + 2 && t3 == basey + 3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = w0 * win[0][j];
+        a += w1 * win[1][j]; a += w2 * win[2][j]; a += w3 * win[3][j];
+        o[j] = a;
+      }
+    } else {                                                             // clamped taps: several read one row
+      const int q1 = t1 - basey, q2 = t2 - basey, q3 = t3 - basey;
+      float wk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wk[k] = (k == 0 ? w0 : 0.f) + (q1 == k ? w1 : 0.f) + (q2 == k ? w2 : 0.f) + (q3 == k ? w3 : 0.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = wk[0] * win[0][j] + wk[1] * win[1][j] + wk[2] * win[2][j] + wk[3] * win[3][j];
+    }
+    if (outok) V8<T>::st(out + cb8_index(n, cb, yo, xo, C8, Ho, Wo), o);
+  }
+}
+
 // adjoint of the bicubic upsample, separable.  One block = a 16 x 16 tile of input (low-res) pixels of one channel block:
 // the (folded) output-gradient window the tile touches (<= 40 x 40) is staged in LDS in the storage type, reduced along
 // y with the transposed tap lists (lanes run over window columns: conflict-free), then along x from a planar f32
@@ -2032,9 +2136,29 @@ int mc_bicubic_fwd_act(const void* x, const float* coef, int32_t act, int32_t n,
   if (act < MC_ACT_NONE || act > MC_ACT_ELU) return MC_EINVAL;
   const int a = (coef == nullptr && act == MC_ACT_NONE) ? -1 : act;      // -1: x is used as it is
   int C8 = (c + 7) / 8;
+  hipStream_t s = (hipStream_t)stream;
+  static const int walk = env_int("MC_BICUBIC_FWD_WALK", 1);
+  if (walk && ho >= hi && wo >= wi) {                                    // upsampling: the row walk (taps span <= 4 rows / 4 columns)
+    const int SW = wo <= 128 ? 128 : (wo <= 256 ? 256 : 512);
+    // one strip when the output row fits the block; else strips of SW - 8 output columns (their input span <= SW - 4)
+    const int fw = wo <= SW ? wo : SW - 8, strips = cdiv(wo, fw);
+    static const int target = env_int("MC_BICUBIC_FWD_WALK_BLOCKS", 1024);
+    const int chunks = max(1, min(cdiv(target, C8 * n * strips), cdiv(ho, 8)));
+    const int rpc = cdiv(ho, chunks);
+    dim3 g(cdiv(ho, rpc) * strips, C8, n);
+#define FWW_(T, S) hipLaunchKernelGGL((k_bicubic_fwd_walk<T, S>), g, dim3(S), 0, s, (const T*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (T*)out, rpc, fw, strips, coef, a)
+#define FWS_(T) do { if (SW == 128) FWW_(T, 128); else if (SW == 256) FWW_(T, 256); else FWW_(T, 512); } while (0)
+    if (dtype == MC_F32) FWS_(float);
+    else if (dtype == MC_BF16) FWS_(bf16_t);
+    else if (dtype == MC_MIX16) FWS_(f16_t);
+    else return MC_EUNSUPPORTED;
+#undef FWS_
+#undef FWW_
+    MC_CHECK_LAUNCH();
+    return MC_OK;
+  }
   int tiles_x = cdiv(wo, FOW), tiles_y = cdiv(ho, FOH);
   dim3 g(tiles_x * tiles_y, C8, n);
-  hipStream_t s = (hipStream_t)stream;
   if (dtype == MC_F32) hipLaunchKernelGGL(k_bicubic_fwd<float>, g, dim3(256), 0, s, (const float*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (float*)out, tiles_x, coef, a);
   else if (dtype == MC_BF16) hipLaunchKernelGGL(k_bicubic_fwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (bf16_t*)out, tiles_x, coef, a);
   else if (dtype == MC_MIX16) hipLaunchKernelGGL(k_bicubic_fwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)x, C8, hi, wi, ho, wo, idx_y, wgt_y, idx_x, wgt_x, (f16_t*)out, tiles_x, coef, a);

@@ -183,6 +183,34 @@ def test_bicubic_adjoint_kernels_vs_torch(kernel, hi, wi, ho, wo, c, dt):
         torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("hi,wi,ho,wo,c,dt", [
+    (253, 256, 506, 512, 8, "f16"), (126, 128, 253, 256, 16, "bf16"), (31, 32, 63, 64, 24, "f32"), (40, 300, 80, 600, 8, "f32"),
+    (20, 24, 60, 72, 8, "f32"), (30, 63, 60, 127, 8, "f16"), (5, 6, 10, 12, 8, "f32"), (7, 9, 7, 9, 8, "f32"), (8, 32, 128, 506, 8, "f32"),
+])
+def test_bicubic_forward_kernel_vs_torch(hi, wi, ho, wo, c, dt):
+    """mc_bicubic_fwd (the row-walk kernel for every upsample) against F.interpolate(mode='bicubic') on the CPU in f64:
+    exact and irregular ratios, column strips, clamped borders, x16 (NewFluidNet's coarsest level)."""
+    import torch.nn.functional as F
+    from pbml_mantle_convection_amd import _lib as L
+    from pbml_mantle_convection_amd.engine import bicubic_tables
+    L.load()
+    N = 2
+    gen = torch.Generator().manual_seed(hi * 1000 + wo + 1)
+    tdt, mcdt = {"f16": (torch.float16, L.MC_MIX16), "bf16": (torch.bfloat16, L.MC_BF16), "f32": (torch.float32, L.MC_F32)}[dt]
+    xq = torch.randn((N, c, hi, wi), generator=gen).to(tdt).float()
+    ref = F.interpolate(xq.double(), size=(ho, wo), mode="bicubic", align_corners=False).float()
+    ty, tx = bicubic_tables(hi, ho), bicubic_tables(wi, wo)
+    dy, dxt = [torch.from_numpy(a).to(DEV) for a in ty[:2]], [torch.from_numpy(a).to(DEV) for a in tx[:2]]
+    c8 = c // 8
+    buf = xq.view(N, c8, 8, hi, wi).permute(0, 1, 3, 4, 2).contiguous().to(DEV).to(tdt)
+    out = torch.full((N, c8, ho, wo, 8), float("nan"), device=DEV).to(tdt)
+    L.call("mc_bicubic_fwd", L.ptr(buf), N, c, hi, wi, ho, wo, L.ptr(dy[0]), L.ptr(dy[1]), L.ptr(dxt[0]), L.ptr(dxt[1]), mcdt, L.ptr(out),
+           L.stream())
+    got = out.float().permute(0, 1, 4, 2, 3).reshape(N, c, ho, wo).cpu()
+    tol = {"f16": 1e-3, "bf16": 8e-3, "f32": 2e-5}[dt]                    # 16-bit: the stored result's own rounding
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+
+
 def test_concat_and_gradient_source_kinds():
     """mc_concat_cb8 (torch.cat of > 2 operands), mc_gsrc_sum, slices of a concatenated gradient and the AvgPool adjoint of a
     plain tensor (SURVEY 8f N1 plumbing) against torch."""
