@@ -353,6 +353,17 @@ int mc_loss_minmax(const float* uvp, int32_t n, int32_t ct, int32_t h, int32_t w
 int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T,
                     int64_t pred_batch_stride, int64_t p_batch_stride, const float* uvp, const float* mm,
                     double* sums, float* gu, float* gv, float* gp, float* gT, void* stream);
+/* mc_loss_fwd_bwd + mc_momentum_residual + mc_momentum_adjoint in ONE launch (the residual signs and the viscosity stay in
+ * LDS), for the Unet branch without the curl head (loss_type 0 / 1, t_grad >= 0; else MC_EUNSUPPORTED).  The predictions come
+ * either as planes (u, v, p, T with batch strides, as mc_loss_fwd_bwd; y_cb8 NULL) or straight from the last convolution's
+ * f32 output y_cb8 [n][ceil(cb8_c / 8)][h][cb8_w][8]: columns cb8_crop .. cb8_crop + w, minus cb8_mean [n][cb8_c] (nullable),
+ * channels u, v, T, p = 0, 1, 2, 3 (Unet.forward :2026-2036) -- which saves the NCHW copy of the network output.  yc [h][w],
+ * paras [n][3], scaler [n] are read when lambda_mom != 0.  Gradients: planes with batch strides g_pbs / g_ppbs
+ * (overwritten). */
+int mc_loss_fused(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T, int64_t pbs, int64_t ppbs,
+                  const float* y_cb8, int32_t cb8_w, int32_t cb8_crop, const float* cb8_mean, int32_t cb8_c, const float* uvp,
+                  const float* mm, const float* yc, const float* paras, const float* scaler, double* sums, float* gu, float* gv,
+                  float* gp, float* gT, int64_t g_pbs, int64_t g_ppbs, void* stream);
 /* Stokes momentum residual (build-defined).  yc [h][w], paras [n][3] =
  * (RaQ, FKT, FKP), scaler [n].  sx, sy, eta_ws: workspaces [n][h][w] f32 (eta_ws receives the viscosity
  * field computed by mc_momentum_residual and is read again by mc_momentum_adjoint). */

@@ -122,6 +122,8 @@ SIGNATURES = {
                                 _vp]),
     "mc_loss_minmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_loss_fwd_bwd": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mc_loss_fused": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _i64, _i64, _vp]),
     "mc_momentum_residual": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_momentum_adjoint": (C.c_int, [_LD, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_loss_finalize": (C.c_int, [_LD, _vp, _vp, _vp]),

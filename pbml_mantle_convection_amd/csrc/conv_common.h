@@ -54,6 +54,11 @@ static inline long wgrad_target_blocks2() {
   if (!v) { const char* e = getenv("MC_WGRAD_BLOCKS2"); v = e ? atol(e) : 512; if (v < 16) v = 16; }
   return v;
 }
+static inline long wgrad_min_slabs() {
+  static long v = 0;
+  if (!v) { const char* e = getenv("MC_WGRAD_MIN_G"); v = e ? atol(e) : 16; if (v < 1) v = 1; }
+  return v;
+}
 static inline long wgrad_target_blocks() {
   static long v = 0;
   if (!v) { const char* e = getenv("MC_WGRAD_BLOCKS"); v = e ? atol(e) : 768; if (v < 16) v = 16; }
@@ -105,7 +110,7 @@ static inline int conv_geom(const mc_conv_desc* d, int tile_h, int tile_w, ConvG
     // one resident wave avoids a half-empty second wave
     const long target = ntw == 1 ? wgrad_target_blocks() : wgrad_target_blocks2();
     G = ntw == 1 ? (target + other - 1) / other : target / other;      // two co-tiles: never spill into a second resident wave
-    if (G < 16) G = 16;
+    if (G < wgrad_min_slabs()) G = wgrad_min_slabs();
     work = (long)g.N * ((g.Ho + 15) / 16) * ((g.Wo + 31) / 32);     // 16 x 32 pixel work items
   } else {
     G = 1024;

@@ -350,6 +350,231 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_loss + k_mom_residual + k_mom_adjoint in ONE pass over the fields (Unet branch without the curl head: the predictions are
+// channels of the network output).  A tile of 16 x 64 pixels with a halo of 2: u, v, their targets, p, T and the viscosity are
+// staged once; the weighted residual signs S_x, S_y of the tile + 1 ring are formed in LDS (never written to memory: the
+// separate kernels moved S_x, S_y and eta through HBM, 0.75 GB per step); then every pixel takes its data, derivative,
+// divergence and momentum-adjoint gradient from LDS and is written once.  Same per-pixel expressions, in the same order, as
+// the three kernels.  CB8IN: the predictions are read straight from the last convolution's f32 output [n][c8][h][cw][8]
+// (columns crop .. crop + w, minus the per-(sample, channel) spatial mean; channels u, v, T, p = 0, 1, 2, 3), which saves the
+// NCHW copy of the network output; else from planes with a batch stride like k_loss.
+constexpr int LF_TH = 16, LF_TW = 64, LF_LH = LF_TH + 4, LF_LW = LF_TW + 4, LF_SH = LF_TH + 2, LF_SW = LF_TW + 2;
+struct FusedIn {
+  const float* u; const float* v; const float* p; const float* T;     // planes (CB8IN = false)
+  const float* y8; const float* mean; int cw, crop, c, c8;           // CB8 f32 network output (CB8IN = true)
+};
+template <bool CB8IN, bool MOM>
+__global__ __launch_bounds__(256) void k_loss_fused(LossGeom g, FusedIn in, const float* __restrict__ uvp,
+                                                    const float* __restrict__ mm, const float* __restrict__ yc,
+                                                    const float* __restrict__ paras, const float* __restrict__ scaler,
+                                                    double* __restrict__ sums, float* __restrict__ gu_, float* __restrict__ gv_,
+                                                    float* __restrict__ gp_, float* __restrict__ gT_, int tiles_x, int tiles) {
+  const int H = g.d.h, W = g.d.w, HW = H * W, n = blockIdx.y;
+  const bool hasP = g.d.p_pred != 0;
+  const float* ut = uvp + ((size_t)n * g.ct + 0) * HW;
+  const float* vt = uvp + ((size_t)n * g.ct + 1) * HW;
+  const float* pt = hasP ? uvp + ((size_t)n * g.ct + 2) * HW : nullptr;
+  const float* Tt = uvp + ((size_t)n * g.ct + (hasP ? 3 : 2)) * HW;
+  float mu = 0.f, mv = 0.f, mT = 0.f, mp = 0.f;
+  if (CB8IN && in.mean) { mu = in.mean[n * in.c]; mv = in.mean[n * in.c + 1]; mT = in.mean[n * in.c + 2]; mp = hasP ? in.mean[n * in.c + 3] : 0.f; }
+  // (u, v, T, p) of pixel (yy, xx) of this sample
+  auto fetch = [&](int yy, int xx, float& fu, float& fv, float& fT, float& fp) {
+    if constexpr (CB8IN) {
+      const float4 q = *reinterpret_cast<const float4*>(in.y8 + ((((size_t)n * in.c8) * H + yy) * in.cw + xx + in.crop) * 8);
+      fu = q.x - mu; fv = q.y - mv; fT = q.z - mT; fp = hasP ? q.w - mp : 0.f;
+    } else {
+      const size_t o = (size_t)yy * W + xx;
+      fu = in.u[(size_t)n * g.pbs + o]; fv = in.v[(size_t)n * g.pbs + o]; fT = in.T[(size_t)n * g.pbs + o];
+      fp = hasP ? in.p[(size_t)n * g.ppbs + o] : 0.f;
+    }
+  };
+  const float k = hasP ? 4.f : 3.f;
+  const float NHW = (float)g.d.n * (float)HW;
+  const float cdat = 1.0f / (k * NHW);
+  float su = 1.f, sv = 1.f;
+  if (g.d.loss_scale) {
+    su = fminf(fmaxf(1.0f / (mm[(n * 3 + 0) * 2 + 1] - mm[(n * 3 + 0) * 2 + 0]), 1.0f), 10.0f);
+    sv = fminf(fmaxf(1.0f / (mm[(n * 3 + 1) * 2 + 1] - mm[(n * 3 + 1) * 2 + 0]), 1.0f), 10.0f);
+  }
+  const float cdu = 126.0f / (k * (float)g.d.n * (float)(H - 2) * (float)W);
+  const float cdv = 126.0f / (k * (float)g.d.n * (float)H * (float)(W - 2));
+  const float wm = 1.0f / ((float)g.d.n * (float)(H - 2) * (float)(W - 2));
+  const float wc = 1.0f / ((float)g.d.n * (float)(H - 2)), wr = 1.0f / ((float)g.d.n * (float)(W - 2));
+  float lnfkt = 0.f, lnfkp = 0.f, s = 1.f;
+  if (MOM) { lnfkt = logf(paras[n * 3 + 1]); lnfkp = logf(paras[n * 3 + 2]); s = scaler[n]; }
+  const float ih = g.d.inv_h;
+  const float cmom = g.d.lambda_mom / ((float)g.d.n * (float)(H - 2) * (float)(W - 2));
+  float a_us = 0, a_up = 0, a_vs = 0, a_vp = 0, a_pp = 0, a_tp = 0, a_du = 0, a_dv = 0;
+  float a_m = 0, a_mx0 = 0, a_mx1 = 0, a_my0 = 0, a_my1 = 0, a_rx = 0, a_ry = 0;
+  __shared__ float us[LF_LH * LF_LW], vs[LF_LH * LF_LW], uts[LF_LH * LF_LW], vts[LF_LH * LF_LW];
+  __shared__ float ps[MOM ? LF_LH * LF_LW : 1], es[MOM ? LF_LH * LF_LW : 1], Ts[LF_LH * LF_LW];
+  __shared__ float sxs[MOM ? LF_SH * LF_SW : 1], sys[MOM ? LF_SH * LF_SW : 1];
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int y0 = (tile / tiles_x) * LF_TH, x0 = (tile % tiles_x) * LF_TW;
+    __syncthreads();                                    // the previous tile has been consumed
+    for (int t = threadIdx.x; t < LF_LH * LF_LW; t += 256) {
+      const int ly = t / LF_LW, lx = t - ly * LF_LW, yy = y0 + ly - 2, xx = x0 + lx - 2;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      float fu = 0.f, fv = 0.f, fT = 0.f, fp = 0.f, e = 0.f, tu = 0.f, tv = 0.f;
+      if (ok) {
+        const size_t o = (size_t)yy * W + xx;
+        fetch(yy, xx, fu, fv, fT, fp);
+        tu = ut[o]; tv = vt[o];
+        if (MOM) e = fminf(fmaxf(expf(-lnfkt * fT + lnfkp * (1.0f - yc[o])), 1e-8f), 1.0f);
+      }
+      us[t] = fu; vs[t] = fv; uts[t] = tu; vts[t] = tv; Ts[t] = fT;
+      if (MOM) { ps[t] = fp; es[t] = e; }
+    }
+    __syncthreads();
+    if (MOM) {
+      // weighted residual signs of the tile + 1 ring (0 outside the interior of the domain); |R| is summed over the tile only
+      for (int t = threadIdx.x; t < LF_SH * LF_SW; t += 256) {
+        const int li = t / LF_SW, lj = t - li * LF_SW, i = y0 + li - 1, j = x0 + lj - 1;
+        float ox = 0.f, oy = 0.f;
+        if (i >= 1 && i <= H - 2 && j >= 1 && j <= W - 2) {
+          const int cc = (li + 1) * LF_LW + lj + 1;
+          auto U = [&](int di, int dj) { return s * us[cc + di * LF_LW + dj]; };
+          auto V = [&](int di, int dj) { return s * vs[cc + di * LF_LW + dj]; };
+          auto P = [&](int di, int dj) { return ps[cc + di * LF_LW + dj]; };
+          auto ET = [&](int di, int dj) { return es[cc + di * LF_LW + dj]; };
+          auto exf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di, dj + 1)); };
+          auto eyf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di + 1, dj)); };
+          auto dVdx = [&](int di, int dj) { return 0.5f * (V(di, dj + 1) - V(di, dj - 1)) * ih; };
+          auto dUdy = [&](int di, int dj) { return 0.5f * (U(di + 1, dj) - U(di - 1, dj)) * ih; };
+          float Fx1 = 2.f * exf(0, 0) * (U(0, 1) - U(0, 0)) * ih;
+          float Fx0 = 2.f * exf(0, -1) * (U(0, 0) - U(0, -1)) * ih;
+          float Ty1 = eyf(0, 0) * ((U(1, 0) - U(0, 0)) * ih + 0.5f * (dVdx(0, 0) + dVdx(1, 0)));
+          float Ty0 = eyf(-1, 0) * ((U(0, 0) - U(-1, 0)) * ih + 0.5f * (dVdx(-1, 0) + dVdx(0, 0)));
+          float Rx = -0.5f * (P(0, 1) - P(0, -1)) * ih + (Fx1 - Fx0) * ih + (Ty1 - Ty0) * ih;
+          float Fy1 = 2.f * eyf(0, 0) * (V(1, 0) - V(0, 0)) * ih;
+          float Fy0 = 2.f * eyf(-1, 0) * (V(0, 0) - V(-1, 0)) * ih;
+          float Tx1 = exf(0, 0) * ((V(0, 1) - V(0, 0)) * ih + 0.5f * (dUdy(0, 0) + dUdy(0, 1)));
+          float Tx0 = exf(0, -1) * ((V(0, 0) - V(0, -1)) * ih + 0.5f * (dUdy(0, -1) + dUdy(0, 0)));
+          float Ry = -0.5f * (P(1, 0) - P(-1, 0)) * ih + (Fy1 - Fy0) * ih + (Tx1 - Tx0) * ih + g.d.ra * Ts[cc];
+          if (li >= 1 && li <= LF_TH && lj >= 1 && lj <= LF_TW) { a_rx += fabsf(Rx); a_ry += fabsf(Ry); }
+          ox = cmom * sgn(Rx); oy = cmom * sgn(Ry);
+        }
+        sxs[t] = ox; sys[t] = oy;
+      }
+      __syncthreads();
+    }
+#pragma unroll 2
+    for (int r = 0; r < LF_TH / 4; ++r) {
+      const int ly = (threadIdx.x >> 6) + 4 * r, lx = threadIdx.x & 63, y = y0 + ly, x = x0 + lx;
+      if (y >= H || x >= W) continue;
+      const int i = y * W + x;
+      const int cc = (ly + 2) * LF_LW + lx + 2;
+      auto U = [&](int dy, int dx) { return us[cc + dy * LF_LW + dx]; };
+      auto V = [&](int dy, int dx) { return vs[cc + dy * LF_LW + dx]; };
+      auto UT = [&](int dy, int dx) { return uts[cc + dy * LF_LW + dx]; };
+      auto VT = [&](int dy, int dx) { return vts[cc + dy * LF_LW + dx]; };
+      auto mass_wsgn = [&](int dy, int dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy < 1 || yy > H - 2 || xx < 1 || xx > W - 2) return 0.f;
+        const float D = 0.5f * (U(dy, dx + 1) - U(dy, dx - 1)) + 0.5f * (V(dy + 1, dx) - V(dy - 1, dx));
+        const float w = g.d.loss_type == 1 ? wm
+                      : (xx == 1 ? wc : 0.f) + (xx == W - 2 ? wc : 0.f) + (yy == 1 ? wr : 0.f) + (yy == H - 2 ? wr : 0.f);
+        return w * sgn(D);
+      };
+      const float bw = (g.d.loss_scale && (y < 2 || y >= H - 2 || x < 2 || x >= W - 2)) ? 11.f : 1.f;
+      float gu = 0.f, gv = 0.f, gp = 0.f, gT = 0.f;
+      {  // data terms
+        float du = UT(0, 0) - U(0, 0), dv = VT(0, 0) - V(0, 0), dT = Tt[i] - Ts[cc];
+        float wu = su * bw, wv = sv * bw;
+        if (!g.d.l2) {
+          a_us += fabsf(du * wu); a_up += fabsf(du);
+          a_vs += fabsf(dv * wv); a_vp += fabsf(dv);
+          a_tp += fabsf(dT);
+          gu -= sgn(du) * wu * cdat; gv -= sgn(dv) * wv * cdat; gT -= sgn(dT) * cdat;
+        } else {
+          a_us += (du * wu) * (du * wu); a_up += du * du;
+          a_vs += (dv * wv) * (dv * wv); a_vp += dv * dv;
+          a_tp += dT * dT;
+          gu -= 2.f * du * wu * wu * cdat; gv -= 2.f * dv * wv * wv * cdat; gT -= 2.f * dT * cdat;
+        }
+        if (hasP) {
+          float pv;
+          if (MOM) pv = ps[cc]; else { float a_, b_, c_; fetch(y, x, a_, b_, c_, pv); }
+          float dp = pt[i] - pv;
+          if (!g.d.l2) { a_pp += fabsf(dp); gp -= sgn(dp) * cdat; }
+          else { a_pp += dp * dp; gp -= 2.f * dp * cdat; }
+        }
+      }
+      if (g.d.loss_derivative) {
+        if (y <= H - 3) {
+          float e = (UT(1, 0) - UT(0, 0)) - (U(1, 0) - U(0, 0));
+          a_du += fabsf(126.0f * e);
+          gu += cdu * sgn(e);
+        }
+        if (y >= 1 && y <= H - 2) {
+          float e = (UT(0, 0) - UT(-1, 0)) - (U(0, 0) - U(-1, 0));
+          gu -= cdu * sgn(e);
+        }
+        if (x <= W - 3) {
+          float e = (VT(0, 1) - VT(0, 0)) - (V(0, 1) - V(0, 0));
+          a_dv += fabsf(126.0f * e);
+          gv += cdv * sgn(e);
+        }
+        if (x >= 1 && x <= W - 2) {
+          float e = (VT(0, 0) - VT(0, -1)) - (V(0, 0) - V(0, -1));
+          gv -= cdv * sgn(e);
+        }
+      }
+      if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+        float D = 0.5f * (U(0, 1) - U(0, -1)) + 0.5f * (V(1, 0) - V(-1, 0));
+        float m = fabsf(D);
+        a_m += m;
+        if (x == 1) a_mx0 += m;
+        if (x == W - 2) a_mx1 += m;
+        if (y == 1) a_my0 += m;
+        if (y == H - 2) a_my1 += m;
+      }
+      if (g.d.loss_type != 0) {
+        gu += 0.5f * (mass_wsgn(0, -1) - mass_wsgn(0, 1));
+        gv += 0.5f * (mass_wsgn(-1, 0) - mass_wsgn(1, 0));
+      }
+      if (g.d.t_grad == 0) gT = 0.f;
+      if (MOM) {
+        const int c = (ly + 1) * LF_SW + lx + 1;           // this pixel in the S tile; eta through cc
+        auto SX = [&](int di, int dj) { return sxs[c + di * LF_SW + dj]; };
+        auto SY = [&](int di, int dj) { return sys[c + di * LF_SW + dj]; };
+        auto ET = [&](int di, int dj) { return es[cc + di * LF_LW + dj]; };
+        auto exf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di, dj + 1)); };
+        auto eyf = [&](int di, int dj) { return 0.5f * (ET(di, dj) + ET(di + 1, dj)); };
+        auto dFx = [&](int di, int dj) { return ih * (SX(di, dj) - SX(di, dj + 1)); };
+        auto dTy = [&](int di, int dj) { return ih * (SX(di, dj) - SX(di + 1, dj)); };
+        auto dFy = [&](int di, int dj) { return ih * (SY(di, dj) - SY(di + 1, dj)); };
+        auto dTx = [&](int di, int dj) { return ih * (SY(di, dj) - SY(di, dj + 1)); };
+        auto E = [&](int di, int dj) { return eyf(di, dj) * dTy(di, dj); };
+        auto Fh = [&](int di, int dj) { return exf(di, dj) * dTx(di, dj); };
+        const float dU = 2.f * ih * (exf(0, -1) * dFx(0, -1) - exf(0, 0) * dFx(0, 0))
+                       + ih * (E(-1, 0) - E(0, 0))
+                       + 0.25f * ih * (Fh(-1, 0) - Fh(1, 0) + Fh(-1, -1) - Fh(1, -1));
+        const float dV = 2.f * ih * (eyf(-1, 0) * dFy(-1, 0) - eyf(0, 0) * dFy(0, 0))
+                       + ih * (Fh(0, -1) - Fh(0, 0))
+                       + 0.25f * ih * (E(0, -1) - E(0, 1) + E(-1, -1) - E(-1, 1));
+        const float dP = -0.5f * ih * (SX(0, -1) - SX(0, 1)) - 0.5f * ih * (SY(-1, 0) - SY(1, 0));
+        gu += s * dU;
+        gv += s * dV;
+        gp += dP;
+        if (g.d.t_grad) gT += g.d.ra * SY(0, 0);
+      }
+      gu_[(size_t)n * g.pbs + i] = gu;
+      gv_[(size_t)n * g.pbs + i] = gv;
+      if (gp_) gp_[(size_t)n * g.ppbs + i] = gp;
+      gT_[(size_t)n * g.pbs + i] = gT;
+    }
+  }
+  BlockSums bs;
+  bs.v[0] = a_us; bs.v[1] = a_up; bs.v[2] = a_vs; bs.v[3] = a_vp; bs.v[4] = a_pp; bs.v[5] = a_tp; bs.v[6] = a_du;
+  bs.v[7] = a_dv; bs.v[8] = a_m; bs.v[9] = a_mx0; bs.v[10] = a_mx1; bs.v[11] = a_my0; bs.v[12] = a_my1; bs.v[13] = a_rx;
+  bs.v[14] = a_ry;
+  const int slots[15] = {MC_S_U_SCALED, MC_S_U_PLAIN, MC_S_V_SCALED, MC_S_V_PLAIN, MC_S_P_PLAIN, MC_S_T_PLAIN, MC_S_DU,
+                         MC_S_DV, MC_S_MASS, MC_S_MASS_X0, MC_S_MASS_X1, MC_S_MASS_Y0, MC_S_MASS_Y1, MC_S_MOMX, MC_S_MOMY};
+  bs.flush<15>(sums, slots);
+}
+
 // on-device batch assembly (ADTimeDataset.__getitem__, datasetio.py:229-280)
 __global__ void k_assemble_adtime(const float* __restrict__ T, const float* __restrict__ uv, const float* __restrict__ t,
                                   const float* __restrict__ paras, const float* __restrict__ paras_nd,
@@ -639,6 +864,44 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
   dim3 grid(min(loss_blocks(d->h * d->w, d->n), tiles), d->n);
   hipLaunchKernelGGL(k_loss, grid, dim3(256), 0, (hipStream_t)stream, g, u, v, d->p_pred ? p : nullptr, T, uvp, mm, sums,
                      gu, gv, d->p_pred ? gp : nullptr, hasT ? gT : nullptr, tiles_x, tiles);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
+int mc_loss_fused(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T, int64_t pbs, int64_t ppbs,
+                  const float* y_cb8, int32_t cb8_w, int32_t cb8_crop, const float* cb8_mean, int32_t cb8_c, const float* uvp,
+                  const float* mm, const float* yc, const float* paras, const float* scaler, double* sums, float* gu, float* gv,
+                  float* gp, float* gT, int64_t g_pbs, int64_t g_ppbs, void* stream) {
+  int rc = check_loss_desc(d);
+  if (rc) return rc;
+  if (d->t_grad < 0 || d->loss_type == 2) return MC_EUNSUPPORTED;       // needs the temperature channel; no curl head
+  if (!uvp || !sums || !gu || !gv || !gT || (d->p_pred && !gp)) return MC_EINVAL;
+  if (d->loss_scale && !mm) return MC_EINVAL;
+  const bool mom = d->lambda_mom != 0.f;
+  if (mom && (!yc || !paras || !scaler)) return MC_EINVAL;
+  FusedIn in{};
+  if (y_cb8) {
+    const int need = d->p_pred ? 4 : 3;
+    if (cb8_c < need || cb8_crop < 0 || cb8_w < d->w + 2 * cb8_crop) return MC_EINVAL;
+    in.y8 = y_cb8; in.mean = cb8_mean; in.cw = cb8_w; in.crop = cb8_crop; in.c = cb8_c; in.c8 = (cb8_c + 7) / 8;
+  } else {
+    if (!u || !v || !T || (d->p_pred && !p)) return MC_EINVAL;
+    in.u = u; in.v = v; in.p = d->p_pred ? p : nullptr; in.T = T;
+  }
+  LossGeom g;
+  // (pbs / ppbs of LossGeom: strides of the plane INPUTS and of the gradient planes; they are the same tensor layout in every
+  // caller of the plane form, and only the gradient strides matter for the CB8 form)
+  if (!y_cb8 && (g_pbs != pbs || g_ppbs != ppbs)) return MC_EINVAL;
+  g.d = *d; g.ct = (d->p_pred ? 3 : 2) + 1; g.pbs = g_pbs; g.ppbs = g_ppbs;
+  const int tiles_x = cdiv(d->w, LF_TW), tiles = tiles_x * cdiv(d->h, LF_TH);
+  static const int total = [] { const char* e = getenv("MC_LOSS_FUSED_BLOCKS"); return e ? atoi(e) : 2048; }();
+  dim3 grid(max(1, min(cdiv(total, d->n), tiles)), d->n);
+  hipStream_t s = (hipStream_t)stream;
+  float* gpp = d->p_pred ? gp : nullptr;
+#define LFK(CB, MO) hipLaunchKernelGGL((k_loss_fused<CB, MO>), grid, dim3(256), 0, s, g, in, uvp, mm, yc, paras, scaler, sums, gu, gv, gpp, gT, tiles_x, tiles)
+  if (y_cb8) { if (mom) LFK(true, true); else LFK(true, false); }
+  else { if (mom) LFK(false, true); else LFK(false, false); }
+#undef LFK
   MC_CHECK_LAUNCH();
   return MC_OK;
 }

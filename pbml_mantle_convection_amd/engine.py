@@ -748,7 +748,16 @@ class Engine:
         return self._tables[key]
 
     # -------------------------------------------------------------- forward
-    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], chan_scale=None, out=None) -> torch.Tensor:
+    def output_cb8(self):
+        """The last convolution's output as the forward pass left it, for consumers that read the CB8 layout themselves
+        (StokesLoss.evaluate(cb8=...)): (buffer [N][C8][H][W + 2 crop][8] f32, per-(sample, channel) spatial means or None,
+        crop, (N, C, H, W)); None when the head does not end in an f32 tensor."""
+        fo = self.T[self.plan[-1]["node"].out]
+        if fo.buf is None or fo.buf.dtype != torch.float32 or fo.C != self.g.c_out:
+            return None
+        return fo.buf, (self.chan_mean if self.g.subtract_mean else None), self.g.crop_w, (self.N, self.g.c_out, self.out_h, self.out_w)
+
+    def forward(self, x: torch.Tensor, params: Dict[str, torch.Tensor], chan_scale=None, out=None, unpack=True) -> torch.Tensor:
         """x: [N, >= c_in, H, W] f32 device tensor (extra trailing channels are ignored)
         -> [N, c_out, H', W'] f32.  chan_scale: optional [c_in] f32 per-channel input scale.  out: optional preallocated
         result (the fused trainer passes one so that a captured step allocates nothing)."""
@@ -842,6 +851,8 @@ class Engine:
                 L.call("mc_gn_finalize", L.ptr(e["part"]), N, e["tiles"], node.c_out, 1, o.H * o.W, 1e-5, None,
                        L.ptr(self.chan_mean), st)
         fo = T[self.plan[-1]["node"].out]
+        if not unpack and self.output_cb8() is not None:      # the caller reads output_cb8() (no NCHW copy of the output)
+            return None
         if out is None:
             out = torch.empty((N, g.c_out, self.out_h, self.out_w), dtype=torch.float32, device=x.device)
         elif tuple(out.shape) != (N, g.c_out, self.out_h, self.out_w) or out.dtype != torch.float32 or not out.is_contiguous():

@@ -8,11 +8,14 @@ backward in one pass over the fields (libmantle_hip: mc_loss_* / mc_momentum_* /
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
 
 from . import _lib as L
+
+FUSED_LOSS = os.environ.get("MANTLE_FUSED_LOSS", "1") != "0"      # mc_loss_fused instead of mc_loss_fwd_bwd + mc_momentum_*
 
 OUT_NAMES = ("loss", "loss_true_u", "loss_true_v", "loss_p", "loss_T", "mass", "momentum", "_")
 
@@ -55,7 +58,7 @@ class StokesLoss:
             self.cu, self.cv, self.cT = (torch.empty((N, H, W), **f32) for _ in range(3))
             self.gcu, self.gcv, self.gcT = (torch.empty((N, H, W), **f32) for _ in range(3))
             self.curl_ws = torch.empty(2 * N * (H - 2) * (W - 2), **f32)
-        if self.lambda_mom != 0.0:
+        if self.lambda_mom != 0.0 and not self.fusable():         # (the one-launch form keeps S_x, S_y and eta in LDS)
             self.sx = torch.empty((N, H, W), **f32)
             self.sy = torch.empty((N, H, W), **f32)
             self.eta = torch.empty((N, H, W), **f32)
@@ -67,24 +70,37 @@ class StokesLoss:
             return 1 + t + (1 if self.p_pred else 0)
         return 2 + t + (1 if self.p_pred else 0)
 
-    def evaluate(self, y: torch.Tensor, uvp: torch.Tensor, yc: Optional[torch.Tensor] = None,
-                 paras: Optional[torch.Tensor] = None, scaler: Optional[torch.Tensor] = None):
+    def fusable(self):
+        """One-launch form (mc_loss_fused): the Unet branch without the curl head."""
+        return FUSED_LOSS and self.has_T and self.loss_type != "curl"
+
+    def evaluate(self, y: Optional[torch.Tensor], uvp: torch.Tensor, yc: Optional[torch.Tensor] = None,
+                 paras: Optional[torch.Tensor] = None, scaler: Optional[torch.Tensor] = None, cb8=None):
         """y: network output [N, C, H, W] f32 (Unet.features / ConvAE output); uvp: truth
         [N, 3|4, H, W] f32.  Returns (out8, gy): out8 = (loss, true_u, true_v, loss_p, loss_T, mass,
-        momentum, 0) on device; gy = d(loss)/d(y)."""
-        L.require_cuda(y, "network output")
+        momentum, 0) on device; gy = d(loss)/d(y).
+        cb8 (only with `fusable()`): (buf, mean, crop, (N, C, H, W)) -- the last convolution's f32 output in the CB8 layout
+        [N][ceil(C / 8)][H][W + 2 crop][8] and its per-(sample, channel) spatial means; y is not read then (may be None)."""
         L.require_cuda(uvp, "uvp")
-        if y.dtype != torch.float32 or not y.is_contiguous():
-            raise RuntimeError("y must be contiguous f32")
+        if cb8 is not None:
+            if not self.fusable():
+                raise RuntimeError("the CB8 form needs the one-launch loss (Unet branch without the curl head)")
+            N, Cc, H, W = cb8[3]
+            dev = cb8[0].device
+        else:
+            L.require_cuda(y, "network output")
+            if y.dtype != torch.float32 or not y.is_contiguous():
+                raise RuntimeError("y must be contiguous f32")
+            N, Cc, H, W = y.shape
+            dev = y.device
         if uvp.dtype != torch.float32 or not uvp.is_contiguous():
             uvp = uvp.float().contiguous()
-        N, Cc, H, W = y.shape
         if Cc < self.channels_needed():
             raise ValueError(f"network output has {Cc} channels, loss needs {self.channels_needed()}")
         ct = (3 if self.p_pred else 2) + (1 if self.has_T else 0)
         if tuple(uvp.shape) != (N, ct, H, W):
             raise ValueError(f"uvp must be [{N},{ct},{H},{W}], got {tuple(uvp.shape)}")
-        self._alloc(N, Cc, H, W, y.device)
+        self._alloc(N, Cc, H, W, dev)
         st = L.stream()
         HW = H * W
         d = L.LossDesc(N, H, W, int(self.p_pred), L.LOSS_TYPES[self.loss_type], int(self.loss_scale),
@@ -93,7 +109,32 @@ class StokesLoss:
         self.sums.zero_()
         if self.loss_scale:
             L.call("mc_loss_minmax", L.ptr(uvp), N, ct, H, W, L.ptr(self.mm), st)
-        yb, gb = y.data_ptr(), self.gy.data_ptr()
+        gb = self.gy.data_ptr()
+        if self.fusable():
+            # channels u, v, T, p  (:2026-2036); every term in one launch
+            gu, gv, gT = gb, gb + 4 * HW, gb + 4 * 2 * HW
+            gp = gb + 4 * 3 * HW if self.p_pred else None
+            if Cc > ct:
+                self.gy.zero_()
+            mom = self.lambda_mom != 0.0
+            if mom:
+                if yc is None or paras is None or scaler is None:
+                    raise ValueError("the momentum term needs yc [H,W], paras [N,3] and scaler [N]")
+                yc = yc.reshape(-1, H, W)[0].float().contiguous()            # ONE depth grid for the whole batch (see below)
+                paras = paras.reshape(N, 3).float().contiguous()
+                scaler = scaler.reshape(N).float().contiguous()
+            args = (L.ptr(uvp), L.ptr(self.mm), L.ptr(yc) if mom else None, L.ptr(paras) if mom else None,
+                    L.ptr(scaler) if mom else None, L.ptr(self.sums), gu, gv, gp, gT, Cc * HW, Cc * HW, st)
+            if cb8 is not None:
+                buf, mean, crop = cb8[:3]
+                L.call("mc_loss_fused", C.byref(d), None, None, None, None, 0, 0, L.ptr(buf), W + 2 * crop, crop, L.ptr(mean), Cc, *args)
+            else:
+                yb = y.data_ptr()
+                L.call("mc_loss_fused", C.byref(d), yb, yb + 4 * HW, yb + 4 * 3 * HW if self.p_pred else None, yb + 4 * 2 * HW,
+                       Cc * HW, Cc * HW, None, 0, 0, None, 0, *args)
+            L.call("mc_loss_finalize", C.byref(d), L.ptr(self.sums), L.ptr(self.out8), st)
+            return self.out8, self.gy
+        yb = y.data_ptr()
         if self.loss_type == "curl" and not self.has_T:
             # NewFluidNet: channel 0 = streamfunction, 1 = p  (reference pytorch_networks_convae.py:1360-1369)
             self.gy.zero_()

@@ -87,6 +87,9 @@ def shard_range(n_items: int, world_size: int, rank: int):
     return int(per * rank), int(per * (rank + 1))
 
 
+CB8_LOSS = os.environ.get("MANTLE_CB8_LOSS", "1") != "0"     # the fused loss reads the network output in its CB8 layout (no NCHW copy)
+
+
 class Trainer:
     _promotion_logged = False
 
@@ -264,8 +267,13 @@ class Trainer:
         ybuf = self._ybuf if eng is m.engine() else None
         if self._rolls():
             gVTp = self._roll_chain(gVTp, paras, lambda x: eng.forward(x, params, self.chan_scale, out=ybuf))
-        y = eng.forward(gVTp, params, self.chan_scale, out=ybuf)
-        out8, gy = loss.evaluate(y, uvp, yc, paras, scaler)
+        # (one-launch loss: it reads the last convolution's output where it lies, and forward() returns None instead of an
+        # NCHW copy when the head ends in an f32 CB8 tensor)
+        y = eng.forward(gVTp, params, self.chan_scale, out=ybuf, unpack=not (loss.fusable() and CB8_LOSS))
+        if y is None:
+            out8, gy = loss.evaluate(None, uvp, yc, paras, scaler, cb8=eng.output_cb8())
+        else:
+            out8, gy = loss.evaluate(y, uvp, yc, paras, scaler)
         if train:
             self.flat.grad.zero_()
             eng.backward(gy, params, self.flat.views(self.flat.grad))

@@ -112,6 +112,49 @@ def test_momentum_residual_matches_oracle(H, W):
         assert bad.double().mean() < 5e-3, (i, float(bad.double().mean()))
 
 
+@pytest.mark.parametrize("H,W,p_pred,lam,ls,ld,loss_type", [
+    (70, 131, True, 1e-6, False, False, "mass"),      # the benched combination, ragged tiles in x and y
+    (37, 64, False, 1e-6, True, True, "mass"),        # no pressure channel, scaled + derivative terms, exact tile width
+    (16, 200, True, 0.0, True, False, "mae"),         # no momentum term
+    (5, 9, True, 1e-6, False, True, "mass"),          # the minimum size: every pixel within two of a wall
+])
+def test_one_launch_loss_equals_the_three_kernels(monkeypatch, H, W, p_pred, lam, ls, ld, loss_type):
+    """mc_loss_fused (plane form and the form that reads the last convolution's CB8 output) against mc_loss_fwd_bwd +
+    mc_momentum_residual + mc_momentum_adjoint: the same per-pixel expressions -> the same gradient field bit for bit, the same
+    sums up to the order of the f64 atomics."""
+    from pbml_mantle_convection_amd import losses
+    B = 3
+    u, v, p, T, uvp = _case(B, H, W, 400, p_pred)
+    paras = fields.sim_parameters(B, 5)
+    paras[:, 1] = 10.0 ** np.array([2.0, 3.0, 4.0])
+    scaler = np.array([30.0, 80.0, 55.0])
+    yc = np.broadcast_to(np.linspace(0, 1, H)[:, None], (H, W)).copy()
+    chans = [u, v, T] + ([p] if p_pred else [])
+    y = dev(np.stack(chans, 1))
+    extra = (dev(yc), dev(paras), dev(scaler)) if lam else (None, None, None)
+    res = {}
+    for mode in ("three", "planes", "cb8"):
+        monkeypatch.setattr(losses, "FUSED_LOSS", mode != "three")
+        Lo = losses.StokesLoss(p_pred, loss_type, ls, ld, lambda_mom=lam)
+        assert Lo.fusable() == (mode != "three")
+        if mode == "cb8":
+            crop, mean = 3, torch.randn(B, len(chans), device=DEV)
+            buf = torch.randn(B, 1, H, W + 2 * crop, 8, device=DEV)          # crop columns and channels 4..7: garbage
+            buf[:, 0, :, crop:crop + W, :len(chans)] = (y + mean[:, :, None, None]).permute(0, 2, 3, 1)
+            # (the kernel subtracts the mean again: compare against the planes rounded the same way)
+            y_eff = buf[:, 0, :, crop:crop + W, :len(chans)].permute(0, 3, 1, 2).contiguous() - mean[:, :, None, None]
+            out8, gy = Lo.evaluate(None, dev(uvp), *extra, cb8=(buf, mean, crop, (B, len(chans), H, W)))
+            monkeypatch.setattr(losses, "FUSED_LOSS", False)
+            ref8, refg = losses.StokesLoss(p_pred, loss_type, ls, ld, lambda_mom=lam).evaluate(y_eff, dev(uvp), *extra)
+            assert torch.equal(gy, refg), float((gy - refg).abs().max())
+            close(out8, ref8, atol=1e-7, rtol=1e-6, what="cb8 sums")
+            continue
+        out8, gy = Lo.evaluate(y, dev(uvp), *extra)
+        res[mode] = (out8.clone(), gy.clone())
+    assert torch.equal(res["planes"][1], res["three"][1]), float((res["planes"][1] - res["three"][1]).abs().max())
+    close(res["planes"][0], res["three"][0], atol=1e-7, rtol=1e-6, what="sums")
+
+
 def test_fused_adam_matches_torch():
     from pbml_mantle_convection_amd import _lib as L
     n = 10007
