@@ -925,18 +925,23 @@ __global__ __launch_bounds__(256, (NTW == 1 && RS >= 2) ? 3 : 2) void k_wgrad_mf
 #ifndef MC_NT1_MT
 #define MC_NT1_MT 8     /* M-tiles per wave of the single-N-tile configuration: 8 -> 4 waves, 4 -> 8 waves per workgroup */
 #endif
-inline Bf16Cfg cfg_for(int c_out) {
+// Tile height 12 (3 M-tiles per wave) where it covers the output rows with fewer padded rows than 16: the input gradients of
+// the deep levels run on the padded domain (35 rows at level 4: 3 x 12 instead of 3 x 16, 67 at level 3: 72 instead of 80,
+// 130 at level 2: 132 instead of 144).  K = 5, several N-tiles per block only.
+inline Bf16Cfg cfg_for(int c_out, int k, int ho) {
+  static const int th12 = getenv("MC_CONV_TH12") ? atoi(getenv("MC_CONV_TH12")) : 1;
   int ntiles = (c_out + 15) / 16;
   int nt = pick_nt(ntiles);
   if (nt == 1) return {16, 32, 1, MC_NT1_MT};
-  if (nt == 2) return {16, 16, 2, 4};
-  return {16, 16, 4, 4};
+  const bool t12 = th12 && k == 5 && (ho + 11) / 12 * 12 < (ho + 15) / 16 * 16;
+  if (nt == 2) return t12 ? Bf16Cfg{12, 16, 2, 3} : Bf16Cfg{16, 16, 2, 4};
+  return t12 ? Bf16Cfg{12, 16, 4, 3} : Bf16Cfg{16, 16, 4, 4};
 }
 
 }  // namespace
 
 int mc_bf16_tile(const mc_conv_desc* d, int* th, int* tw) {
-  Bf16Cfg c = cfg_for(d->c_out);
+  Bf16Cfg c = cfg_for(d->c_out, d->k, d->h + 2 * d->pad - d->k + 1);
   *th = c.th; *tw = c.tw;
   return MC_OK;
 }
@@ -971,8 +976,9 @@ int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hip
 }
 
 const char* mc_bf16_kernel_name(const ConvGeom& g) {
-  Bf16Cfg c = cfg_for(g.Cout);
+  Bf16Cfg c = cfg_for(g.Cout, g.K, g.Ho);
   if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,16,32,1,8,true>" : "k_conv_mfma_bf16<3,16,32,1,8,true>";
+  if (g.K == 5 && c.th == 12) return c.nt == 2 ? "k_conv_mfma_bf16<5,12,16,2,3,false>" : "k_conv_mfma_bf16<5,12,16,4,3,false>";
   if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4,false>" : "k_conv_mfma_bf16<5,16,16,4,4,false>");
   return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4,false>" : "k_conv_mfma_bf16<3,16,16,4,4,false>");
 }
@@ -980,7 +986,7 @@ const char* mc_bf16_kernel_name(const ConvGeom& g) {
 int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
                    void* y1, float* part, const ConvFuse& fz, int fuse, hipStream_t s) {
   const ConvGeom& g = g_in;
-  Bf16Cfg c = cfg_for(g.Cout);
+  Bf16Cfg c = cfg_for(g.Cout, g.K, g.Ho);
   int nt_total = (g.Cout + 15) / 16;
   int groups = (nt_total + c.nt - 1) / c.nt;
   int items = g.tiles * g.N;
@@ -1002,7 +1008,9 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
   if (g.out_f32) {
     if (g.K == 5) LAUNCH(5, 16, 32, 1, MC_NT1_MT, true); else if (g.K == 3) LAUNCH(3, 16, 32, 1, MC_NT1_MT, true); else return MC_EUNSUPPORTED;
   } else if (g.K == 5) {
-    if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH(5, 16, 16, 4, 4, false);
+    if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT, false);
+    else if (c.th == 12) { if (c.nt == 2) LAUNCH(5, 12, 16, 2, 3, false); else LAUNCH(5, 12, 16, 4, 3, false); }
+    else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH(5, 16, 16, 4, 4, false);
   } else if (g.K == 3) {
     if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4, false); else LAUNCH(3, 16, 16, 4, 4, false);
   } else {

@@ -224,6 +224,8 @@ def test_training_steps_bf16_vs_golden(golden, tag):
     (32, 64, 32, 5, 8, (12, 17)),     # N = 96 (NT = 2 x 3 groups), K over 32 channels (2 chunks)
     (64, 128, 64, 5, 16, (9, 10)),    # N = 192 (NT = 4 x 3 groups)
     (8, 0, 4, 3, 0, (14, 15)),        # tiny channel counts, 3x3
+    (32, 0, 32, 5, 8, (31, 33)),      # padded domain of 35 rows: the 12-row tile (3 x 12 instead of 3 x 16), NT = 2
+    (64, 128, 64, 5, 16, (17, 18)),   # 21 rows: 12-row tiles with NT = 4, three N-groups
 ])
 def test_input_gradient_kernel_direct(dtype_name, ci0, ci1, co, k, h, hw):
     """mc_conv2d in input-gradient mode (padded domain, rotated/transposed bank, split outputs) against
