@@ -359,7 +359,10 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
 // the three kernels.  CB8IN: the predictions are read straight from the last convolution's f32 output [n][c8][h][cw][8]
 // (columns crop .. crop + w, minus the per-(sample, channel) spatial mean; channels u, v, T, p = 0, 1, 2, 3), which saves the
 // NCHW copy of the network output; else from planes with a batch stride like k_loss.
-constexpr int LF_TH = 16, LF_TW = 64, LF_LH = LF_TH + 4, LF_LW = LF_TW + 4, LF_SH = LF_TH + 2, LF_SW = LF_TW + 2;
+// (tile rows, measured at 32 x 506 x 506: 16 -> 252 us, 8 -> 219 us: the kernel is bound by the latency of its dependent LDS
+// reads, not by bytes or arithmetic -- 28 KB of LDS and 123 VGPRs give 4 resident blocks per CU; forcing 5 with a register cap
+// spilled (230 us); forming every face value once in LDS (four more arrays, three more barriers per tile) cost 314 us)
+constexpr int LF_TH = 8, LF_TW = 64, LF_LH = LF_TH + 4, LF_LW = LF_TW + 4, LF_SH = LF_TH + 2, LF_SW = LF_TW + 2;
 struct FusedIn {
   const float* u; const float* v; const float* p; const float* T;     // planes (CB8IN = false)
   const float* y8; const float* mean; int cw, crop, c, c8;           // CB8 f32 network output (CB8IN = true)
