@@ -1833,9 +1833,10 @@ int mc_avgpool_fwd(const void* x, int32_t n, int32_t c, int32_t h, int32_t w, in
 
 int32_t mc_gn_bwd_blocks(int32_t h, int32_t w) {
   static int env_vpt = env_int("MC_GN_RED_VPT", 0);
-  // vectors per thread of the phase-1 reduction: 32 on large images (fewer, longer blocks amortise the 16-value block
-  // reduction: 161 -> 140 us at 506 x 512), 8 otherwise (tools/bench_gn.py sweep)
-  const int vpt = env_vpt > 0 ? env_vpt : ((long)h * w >= 200000 ? 32 : 8);
+  // vectors per thread of the phase-1 reduction.  Round 2 used 32 on large images (measured on the kernel alone); inside the
+  // round-3 step 8 is better everywhere (whole step at 32 x 506 x 512, 8 / 16 / 32 / 64: 10.15 / 10.19 / 10.33 / 10.57 ms
+  // mixed, 10.10 / 10.10 / 10.31 plain bf16: the two-source reduction of the encoder's last layers wants many short blocks)
+  const int vpt = env_vpt > 0 ? env_vpt : 8;
   int b = cdiv(h * w, 256 * vpt);
   if (b > 128) b = 128;
   if (b < 1) b = 1;
