@@ -433,6 +433,7 @@ class Engine:
         # while every cross-queue dependency of the captured step costs 12-17 us (tools/step_timeline.py): one stream wins.
         # (Round 1 measured the opposite, -0.25 ms for 1, with the slower filter-gradient kernel of that time.)
         self.overlap_wgrad = int(os.environ.get("MANTLE_OVERLAP_WGRAD", "0"))
+        self.overlap_pack = int(os.environ.get("MANTLE_OVERLAP_PACK", "0"))    # the three bank-packing launches beside the input pack
         # bit 0: GroupNorm + activation applied by the consumers on load (conv, filter gradient, bicubic) instead of a
         # stand-alone pass that materialises the activated tensor; bit 1: the GroupNorm-backward reduction fused into the
         # epilogue of the input-gradient launch (single-consumer tensors).  0 = the round-1 unfused chain (A/B, tests).
@@ -772,7 +773,7 @@ class Engine:
         st = L.stream()
         g, T = self.g, self.T
         act = L.ACTS[g.act]
-        if self.overlap_wgrad:
+        if self.overlap_wgrad or self.overlap_pack:
             # filter banks are packed on the side stream while the input is converted on the main one
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
@@ -780,7 +781,7 @@ class Engine:
                 self._pack_all_banks(params, L.stream())
         L.call("mc_pack_nchw", L.ptr(x), N, g.c_in, Ci, H, W, g.in_pad_w, self.mode, L.ptr(chan_scale), self.mc_dtype,
                L.ptr(T[0].buf), st)
-        if self.overlap_wgrad:
+        if self.overlap_wgrad or self.overlap_pack:
             main.wait_stream(self.side)
         else:
             self._pack_all_banks(params, st)
