@@ -934,6 +934,12 @@ inline Bf16Cfg cfg_for(int c_out, int k, int ho) {
   int nt = pick_nt(ntiles);
   if (nt == 1) return {16, 32, 1, MC_NT1_MT};
   const bool t12 = th12 && k == 5 && (ho + 11) / 12 * 12 < (ho + 15) / 16 * 16;
+  // (24-row tiles, 6 M-tiles per wave -- each filter fragment feeds 6 MFMAs instead of 3 or 4 -- measured +0.04 ms where they
+  // cover the rows as tightly as 12 / 16 and +0.2 ms everywhere: fragment reuse is not what bounds these launches)
+  // 8-row tiles (2 M-tiles per wave, twice the work-groups) for images of <= 40 output rows (level 4: 31 forward, 35 on the
+  // padded domain): -0.02 ... -0.05 ms per step; at <= 70 rows +-0, at <= 140 rows +0.15 ms; 4-row tiles +0.2 ms
+  static const int th8 = getenv("MC_CONV_TH8") ? atoi(getenv("MC_CONV_TH8")) : 40;
+  if (th8 && k == 5 && ho <= th8) return nt == 2 ? Bf16Cfg{8, 16, 2, 2} : Bf16Cfg{8, 16, 4, 2};
   if (nt == 2) return t12 ? Bf16Cfg{12, 16, 2, 3} : Bf16Cfg{16, 16, 2, 4};
   return t12 ? Bf16Cfg{12, 16, 4, 3} : Bf16Cfg{16, 16, 4, 4};
 }
@@ -979,6 +985,7 @@ const char* mc_bf16_kernel_name(const ConvGeom& g) {
   Bf16Cfg c = cfg_for(g.Cout, g.K, g.Ho);
   if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,16,32,1,8,true>" : "k_conv_mfma_bf16<3,16,32,1,8,true>";
   if (g.K == 5 && c.th == 12) return c.nt == 2 ? "k_conv_mfma_bf16<5,12,16,2,3,false>" : "k_conv_mfma_bf16<5,12,16,4,3,false>";
+  if (g.K == 5 && c.th == 8) return c.nt == 2 ? "k_conv_mfma_bf16<5,8,16,2,2,false>" : "k_conv_mfma_bf16<5,8,16,4,2,false>";
   if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4,false>" : "k_conv_mfma_bf16<5,16,16,4,4,false>");
   return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4,false>" : "k_conv_mfma_bf16<3,16,16,4,4,false>");
 }
@@ -1010,6 +1017,7 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
   } else if (g.K == 5) {
     if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT, false);
     else if (c.th == 12) { if (c.nt == 2) LAUNCH(5, 12, 16, 2, 3, false); else LAUNCH(5, 12, 16, 4, 3, false); }
+    else if (c.th == 8) { if (c.nt == 2) LAUNCH(5, 8, 16, 2, 2, false); else LAUNCH(5, 8, 16, 4, 2, false); }
     else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH(5, 16, 16, 4, 4, false);
   } else if (g.K == 3) {
     if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4, false); else LAUNCH(3, 16, 16, 4, 4, false);
