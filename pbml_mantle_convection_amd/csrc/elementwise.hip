@@ -238,6 +238,14 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static int gn_fwd_vpt() { static int v = env_int("MC_GN_FWD_VPT", 8); return v; }
 // rows per block of the backward-apply kernel (tools/bench_gn.py sweep on MI355X): 8 rows for wide images, more for narrow
 // ones so that a block still streams >= 16 vectors per thread
+// threads per block of the one-launch GroupNorm kernels (one block per (sample, channel block)): at 73-88 registers a
+// 1024-thread block fills a CU alone, so a grid of more blocks than CUs (level 4: 16 channel blocks x 32 samples) ran in two
+// rounds; 512-thread blocks sit two to a CU and finish in one (each thread then walks two pixels instead of one)
+static int gn_small_threads(int blocks) {
+  static int v = env_int("MC_GN_SMALL_THREADS", 0);
+  if (v >= 512) return v;                       // (k_gn_act_small needs one wave per group of a channel block: >= 8 waves)
+  return blocks > 256 ? 512 : 1024;             // in-step A/B, 1024 / auto / 512 / 256: 9.71 / 9.67 / 9.67 / 9.76 ms
+}
 static int gn_apply_rows(int h, int w) { static int v = env_int("MC_GN_ROWS", 0); if (v > 0) return v; return w > 256 ? GN_ROWS : (w > 32 ? 16 : 32); }
 
 struct GnArgs {
@@ -1942,7 +1950,7 @@ int mc_gn_act_fwd_small(const void* y, const float* stat_partials, int32_t tiles
   if (a.cpg != 1 && a.cpg != 2 && a.cpg != 4 && a.cpg != 8) return MC_EUNSUPPORTED;
   dim3 g(a.C8, n);
   hipStream_t s = (hipStream_t)stream;
-#define FS(T, P) hipLaunchKernelGGL((k_gn_act_small<T, P>), g, dim3(1024), 0, s, a, (const T*)y, stat_partials, tiles, eps, stats_out, (T*)a_out, (T*)pooled)
+#define FS(T, P) hipLaunchKernelGGL((k_gn_act_small<T, P>), g, dim3(gn_small_threads(a.C8 * n)), 0, s, a, (const T*)y, stat_partials, tiles, eps, stats_out, (T*)a_out, (T*)pooled)
   if (dtype == MC_F32) { if (pool == 1) FS(float, 1); else FS(float, 2); }
   else if (dtype == MC_BF16) { if (pool == 1) FS(bf16_t, 1); else FS(bf16_t, 2); }
   else if (dtype == MC_MIX16) { if (pool == 1) FS(f16_t, 1); else FS(f16_t, 2); }
@@ -1965,8 +1973,8 @@ int mc_gn_act_bwd_small(const void* y, int32_t n, int32_t c, int32_t h, int32_t 
   hipStream_t s = (hipStream_t)stream;
   const mc_grad_src s0 = gsrc_or_none(g0), s1 = gsrc_or_none(g1);
   const int CP = a.C8 * 8;
-#define SM(T, GK) hipLaunchKernelGGL((k_gn_bwd_small<T, GK>), g, dim3(1024), 0, s, a, (const T*)y, s0, s1, (T*)dy, chan_sums, CP)
-#define SMH(GK) hipLaunchKernelGGL((k_gn_bwd_small<bf16_t, GK, f16_t>), g, dim3(1024), 0, s, a, (const f16_t*)y, s0, s1, (bf16_t*)dy, chan_sums, CP)
+#define SM(T, GK) hipLaunchKernelGGL((k_gn_bwd_small<T, GK>), g, dim3(gn_small_threads(a.C8 * n)), 0, s, a, (const T*)y, s0, s1, (T*)dy, chan_sums, CP)
+#define SMH(GK) hipLaunchKernelGGL((k_gn_bwd_small<bf16_t, GK, f16_t>), g, dim3(gn_small_threads(a.C8 * n)), 0, s, a, (const f16_t*)y, s0, s1, (bf16_t*)dy, chan_sums, CP)
   if (dtype == MC_F32) SM(float, 0);
   else if (dtype == MC_BF16) {
     switch (gkind_of(s0, s1)) { case 1: SM(bf16_t, 1); break; case 2: SM(bf16_t, 2); break; case 3: SM(bf16_t, 3); break; default: SM(bf16_t, 0); }
