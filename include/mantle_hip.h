@@ -193,6 +193,10 @@ int mc_conv2d_wgrad_finalize_batched(const mc_conv_desc* descs, const void* cons
  * touches only the O(p (H+W)) border pixels. */
 int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode,
                    int32_t dtype, void* stream);
+/* The same for the two input-gradient outputs of a convolution over concatenated sources (same hs x ws, c0 and c1 channels)
+ * in one launch; buf1 NULL = one buffer. */
+int mc_fold_padded2(void* buf0, int32_t c0, void* buf1, int32_t c1, int32_t n, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode,
+                    int32_t dtype, void* stream);
 /* Companion of mc_conv2d_fused's epilogue for reflect / replicate padding: folds the halo onto the frame pixels (within
  * pad+1 of the border) like mc_fold_padded, then turns them into dz = dA * act'(z) in place and writes their partial sums
  * into `partials` [n][mc_fold_blocks()][c8*8][2] (the caller passes the slots behind the conv tiles' of the same table). */

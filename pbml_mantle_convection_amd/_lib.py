@@ -80,6 +80,7 @@ SIGNATURES = {
     "mc_pack_weights_batched": (C.c_int, [_CD, _vp, _vp, _vp, _i32, _vp]),
     "mc_conv2d_wgrad_finalize_batched": (C.c_int, [_CD, _vp, _vp, _vp, _i32, _vp]),
     "mc_fold_padded": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mc_fold_padded2": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mc_gn_partials": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_gn_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "mc_gn_act_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,

@@ -809,9 +809,13 @@ __global__ void k_gn_param_grads(GpTable t) {
 
 // in-place adjoint of F.pad on a padded-domain gradient: one thread per border TARGET pixel (a pixel of the
 // interior frame of thickness p+1) gathers its halo sources; sources are halo positions only, so no hazards.
+// (buf1 / C8a: a second buffer of the same H x W -- the two input-gradient outputs of a convolution over concatenated
+// sources -- folded by the same launch: channel blocks >= C8a belong to buf1, which has C8 - C8a of them)
 template <typename T>
-__global__ void k_fold_padded(T* __restrict__ buf, int C8, int H, int W, int p, int mode, int all) {
-  const int n = blockIdx.z, cb = blockIdx.y;
+__global__ void k_fold_padded(T* __restrict__ buf, int C8, int H, int W, int p, int mode, int all, T* __restrict__ buf1, int C8a) {
+  const int n = blockIdx.z;
+  int cb = blockIdx.y;
+  if (buf1 && cb >= C8a) { buf = buf1; cb -= C8a; C8 -= C8a; } else if (buf1) { C8 = C8a; }
   const int t = p + 1;
   const int band = all ? H * W : 2 * t * W;         // top + bottom bands (all columns); tiny images: every pixel
   const int side = all ? 0 : (H - 2 * t) * 2 * t;   // left + right bands of the remaining rows
@@ -2007,20 +2011,26 @@ int mc_gn_param_grads_batched(const float* const* chan_sums, const int32_t* n, c
   return MC_OK;
 }
 
-int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode, int32_t dtype,
-                   void* stream) {
-  if (!buf || n <= 0 || c <= 0 || hs <= 0 || ws <= 0 || pad < 0 || pad > 2) return MC_EINVAL;
+int mc_fold_padded2(void* buf0, int32_t c0, void* buf1, int32_t c1, int32_t n, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode,
+                    int32_t dtype, void* stream) {
+  if (!buf0 || n <= 0 || c0 <= 0 || hs <= 0 || ws <= 0 || pad < 0 || pad > 2 || (buf1 && c1 <= 0)) return MC_EINVAL;
   if (pad == 0 || pad_mode == MC_PAD_ZEROS) return MC_OK;
-  int C8 = (c + 7) / 8, t = pad + 1;
+  const int C8a = (c0 + 7) / 8, C8 = C8a + (buf1 ? (c1 + 7) / 8 : 0), t = pad + 1;
   int all = (hs < 2 * t || ws < 2 * t) ? 1 : 0;
   int total = all ? hs * ws : 2 * t * ws + (hs - 2 * t) * 2 * t;
   dim3 g(cdiv(total, 256), C8, n);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded<float>, g, dim3(256), 0, s, (float*)buf, C8, hs, ws, pad, pad_mode, all);
-  else if (mc_is16(dtype)) hipLaunchKernelGGL(k_fold_padded<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf, C8, hs, ws, pad, pad_mode, all);
+  if (dtype == MC_F32) hipLaunchKernelGGL(k_fold_padded<float>, g, dim3(256), 0, s, (float*)buf0, C8, hs, ws, pad, pad_mode, all, (float*)buf1, C8a);
+  else if (mc_is16(dtype)) hipLaunchKernelGGL(k_fold_padded<bf16_t>, g, dim3(256), 0, s, (bf16_t*)buf0, C8, hs, ws, pad, pad_mode, all, (bf16_t*)buf1, C8a);
   else return MC_EUNSUPPORTED;
   MC_CHECK_LAUNCH();
   return MC_OK;
+}
+
+int mc_fold_padded(void* buf, int32_t n, int32_t c, int32_t hs, int32_t ws, int32_t pad, int32_t pad_mode, int32_t dtype,
+                   void* stream) {
+  if (!buf || c <= 0) return MC_EINVAL;
+  return mc_fold_padded2(buf, c, nullptr, 0, n, hs, ws, pad, pad_mode, dtype, stream);
 }
 
 static void fold_shape(int hs, int ws, int pad, int& all, int& total) {

@@ -1060,11 +1060,17 @@ class Engine:
                 L.call("mc_conv2d", C.byref(e["ddesc"]), L.ptr(dY), None, L.ptr(e["dbank"]), None, L.ptr(dxp[0]),
                        L.ptr(dxp[1]) if len(dxp) > 1 else None, None, st)
                 self._probe_end(e["ddesc"], "dgrad " + node.name)
-                for s, buf in zip(srcs, dxp):
-                    if s.requires_grad:
-                        # adjoint of the padding: fold the halo onto the interior once, consumers read at an offset
+                # adjoint of the padding: fold the halo onto the interior once, consumers read at an offset (the two outputs of
+                # a convolution over concatenated sources in one launch)
+                live = [(s, buf) for s, buf in zip(srcs, dxp) if s.requires_grad]
+                if len(live) == 2 and (live[0][0].H, live[0][0].W) == (live[1][0].H, live[1][0].W):
+                    L.call("mc_fold_padded2", L.ptr(live[0][1]), live[0][0].C, L.ptr(live[1][1]), live[1][0].C, N, live[0][0].H,
+                           live[0][0].W, node.pad, self.mode, self.mc_gdtype, st)
+                else:
+                    for s, buf in live:
                         L.call("mc_fold_padded", L.ptr(buf), N, s.C, s.H, s.W, node.pad, self.mode, self.mc_gdtype, st)
-                        s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
+                for s, buf in live:
+                    s.gsrcs.append(L.GradSrc(L.ptr(buf), L.GSRC_PADFOLD, node.pad, self.mode, 1, s.H, s.W))
         main.wait_stream(self.side)
         if gp_jobs:
             n = len(gp_jobs)
