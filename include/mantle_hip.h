@@ -367,7 +367,12 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
 int mc_loss_fused(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T, int64_t pbs, int64_t ppbs,
                   const float* y_cb8, int32_t cb8_w, int32_t cb8_crop, const float* cb8_mean, int32_t cb8_c, const float* uvp,
                   const float* mm, const float* yc, const float* paras, const float* scaler, double* sums, float* gu, float* gv,
-                  float* gp, float* gT, int64_t g_pbs, int64_t g_ppbs, void* stream);
+                  float* gp, float* gT, int64_t g_pbs, int64_t g_ppbs, float* gsum_part, void* stream);
+/* gsum_part (nullable): [n][mc_loss_fused_blocks(n, h, w)][4] per-block sums of the gradient planes (u, v, T, p; deterministic
+ * order); mc_partial_sums_finalize turns them into out[n * c + j] = scale * (sum over the blocks), j < c <= 4 -- the spatial
+ * means the adjoint of the network's mean subtraction needs (mc_pack_grad_nchw), without a pass over the gradient tensor. */
+int32_t mc_loss_fused_blocks(int32_t n, int32_t h, int32_t w);
+int mc_partial_sums_finalize(const float* part, int32_t n, int32_t blocks, int32_t c, float scale, float* out, void* stream);
 /* Stokes momentum residual (build-defined).  yc [h][w], paras [n][3] =
  * (RaQ, FKT, FKP), scaler [n].  sx, sy, eta_ws: workspaces [n][h][w] f32 (eta_ws receives the viscosity
  * field computed by mc_momentum_residual and is read again by mc_momentum_adjoint). */

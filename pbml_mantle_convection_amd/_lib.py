@@ -124,7 +124,9 @@ SIGNATURES = {
     "mc_loss_minmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mc_loss_fwd_bwd": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_loss_fused": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _vp, _vp, _i64, _i64, _vp]),
+                                _vp, _vp, _i64, _i64, _vp, _vp]),
+    "mc_loss_fused_blocks": (_i32, [_i32, _i32, _i32]),
+    "mc_partial_sums_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _vp, _vp]),
     "mc_momentum_residual": (C.c_int, [_LD, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_momentum_adjoint": (C.c_int, [_LD, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mc_loss_finalize": (C.c_int, [_LD, _vp, _vp, _vp]),
@@ -133,7 +135,7 @@ SIGNATURES = {
 
 # entry points whose return value is a quantity, not a status code
 VALUE_RETURNING = {"mc_version", "mc_strerror", "mc_conv_kernel_name", "mc_packed_weight_bytes", "mc_conv_bank_read_extent", "mc_conv_tiles",
-                   "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks", "mc_fold_blocks"}
+                   "mc_wgrad_partial_bytes", "mc_gn_bwd_blocks", "mc_fold_blocks", "mc_loss_fused_blocks"}
 
 _lib = None
 

@@ -350,6 +350,16 @@ __global__ __launch_bounds__(256) void k_mom_adjoint(MomGeom g, const float* __r
   }
 }
 
+// out[n * c + j] = scale * sum_b part[n][b][j] (b in order: deterministic), j < c <= 4: the per-block sums of k_loss_fused
+__global__ void k_partial_sums_finalize(const float* __restrict__ part, int n, int blocks, int c, float scale, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const int s = i / c, j = i - s * c;
+  float a = 0.f;
+  for (int b = 0; b < blocks; ++b) a += part[((size_t)s * blocks + b) * 4 + j];
+  out[i] = a * scale;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_loss + k_mom_residual + k_mom_adjoint in ONE pass over the fields (Unet branch without the curl head: the predictions are
 // channels of the network output).  A tile of 16 x 64 pixels with a halo of 2: u, v, their targets, p, T and the viscosity are
@@ -372,9 +382,11 @@ __global__ __launch_bounds__(256) void k_loss_fused(LossGeom g, FusedIn in, cons
                                                     const float* __restrict__ mm, const float* __restrict__ yc,
                                                     const float* __restrict__ paras, const float* __restrict__ scaler,
                                                     double* __restrict__ sums, float* __restrict__ gu_, float* __restrict__ gv_,
-                                                    float* __restrict__ gp_, float* __restrict__ gT_, int tiles_x, int tiles) {
+                                                    float* __restrict__ gp_, float* __restrict__ gT_, int tiles_x, int tiles,
+                                                    float* __restrict__ gsum_part) {
   const int H = g.d.h, W = g.d.w, HW = H * W, n = blockIdx.y;
   const bool hasP = g.d.p_pred != 0;
+  float q_u = 0.f, q_v = 0.f, q_T = 0.f, q_p = 0.f;             // this thread's share of the spatial sums of the gradient planes
   const float* ut = uvp + ((size_t)n * g.ct + 0) * HW;
   const float* vt = uvp + ((size_t)n * g.ct + 1) * HW;
   const float* pt = hasP ? uvp + ((size_t)n * g.ct + 2) * HW : nullptr;
@@ -567,7 +579,20 @@ __global__ __launch_bounds__(256) void k_loss_fused(LossGeom g, FusedIn in, cons
       gv_[(size_t)n * g.pbs + i] = gv;
       if (gp_) gp_[(size_t)n * g.ppbs + i] = gp;
       gT_[(size_t)n * g.pbs + i] = gT;
+      q_u += gu; q_v += gv; q_T += gT; q_p += gp;
     }
+  }
+  if (gsum_part) {
+    // per-block sums of the four gradient planes in a fixed order (thread -> wave -> block): the adjoint of the network's
+    // spatial-mean subtraction needs their means, which saves a pass over the gradient tensor (mc_partial_sums_finalize)
+    __shared__ float qred[4][4];
+    const float r0 = wave_sum(q_u), r1 = wave_sum(q_v), r2 = wave_sum(q_T), r3 = wave_sum(q_p);
+    if ((threadIdx.x & 63) == 0) { float* q = qred[threadIdx.x >> 6]; q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+      gsum_part[((size_t)n * gridDim.x + blockIdx.x) * 4 + threadIdx.x] =
+          ((qred[0][threadIdx.x] + qred[1][threadIdx.x]) + qred[2][threadIdx.x]) + qred[3][threadIdx.x];
+    __syncthreads();
   }
   BlockSums bs;
   bs.v[0] = a_us; bs.v[1] = a_up; bs.v[2] = a_vs; bs.v[3] = a_vp; bs.v[4] = a_pp; bs.v[5] = a_tp; bs.v[6] = a_du;
@@ -871,10 +896,24 @@ int mc_loss_fwd_bwd(const mc_loss_desc* d, const float* u, const float* v, const
   return MC_OK;
 }
 
+int32_t mc_loss_fused_blocks(int32_t n, int32_t h, int32_t w) {
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  static const int total = [] { const char* e = getenv("MC_LOSS_FUSED_BLOCKS"); return e ? atoi(e) : 2048; }();
+  const int tiles = cdiv(w, LF_TW) * cdiv(h, LF_TH);
+  return max(1, min(cdiv(total, n), tiles));
+}
+
+int mc_partial_sums_finalize(const float* part, int32_t n, int32_t blocks, int32_t c, float scale, float* out, void* stream) {
+  if (!part || !out || n <= 0 || blocks <= 0 || c <= 0 || c > 4) return MC_EINVAL;
+  hipLaunchKernelGGL(k_partial_sums_finalize, dim3(cdiv(n * c, 128)), dim3(128), 0, (hipStream_t)stream, part, n, blocks, c, scale, out);
+  MC_CHECK_LAUNCH();
+  return MC_OK;
+}
+
 int mc_loss_fused(const mc_loss_desc* d, const float* u, const float* v, const float* p, const float* T, int64_t pbs, int64_t ppbs,
                   const float* y_cb8, int32_t cb8_w, int32_t cb8_crop, const float* cb8_mean, int32_t cb8_c, const float* uvp,
                   const float* mm, const float* yc, const float* paras, const float* scaler, double* sums, float* gu, float* gv,
-                  float* gp, float* gT, int64_t g_pbs, int64_t g_ppbs, void* stream) {
+                  float* gp, float* gT, int64_t g_pbs, int64_t g_ppbs, float* gsum_part, void* stream) {
   int rc = check_loss_desc(d);
   if (rc) return rc;
   if (d->t_grad < 0 || d->loss_type == 2) return MC_EUNSUPPORTED;       // needs the temperature channel; no curl head
@@ -896,12 +935,11 @@ int mc_loss_fused(const mc_loss_desc* d, const float* u, const float* v, const f
   // caller of the plane form, and only the gradient strides matter for the CB8 form)
   if (!y_cb8 && (g_pbs != pbs || g_ppbs != ppbs)) return MC_EINVAL;
   g.d = *d; g.ct = (d->p_pred ? 3 : 2) + 1; g.pbs = g_pbs; g.ppbs = g_ppbs;
+  dim3 grid(mc_loss_fused_blocks(d->n, d->h, d->w), d->n);
   const int tiles_x = cdiv(d->w, LF_TW), tiles = tiles_x * cdiv(d->h, LF_TH);
-  static const int total = [] { const char* e = getenv("MC_LOSS_FUSED_BLOCKS"); return e ? atoi(e) : 2048; }();
-  dim3 grid(max(1, min(cdiv(total, d->n), tiles)), d->n);
   hipStream_t s = (hipStream_t)stream;
   float* gpp = d->p_pred ? gp : nullptr;
-#define LFK(CB, MO) hipLaunchKernelGGL((k_loss_fused<CB, MO>), grid, dim3(256), 0, s, g, in, uvp, mm, yc, paras, scaler, sums, gu, gv, gpp, gT, tiles_x, tiles)
+#define LFK(CB, MO) hipLaunchKernelGGL((k_loss_fused<CB, MO>), grid, dim3(256), 0, s, g, in, uvp, mm, yc, paras, scaler, sums, gu, gv, gpp, gT, tiles_x, tiles, gsum_part)
   if (y_cb8) { if (mom) LFK(true, true); else LFK(true, false); }
   else { if (mom) LFK(false, true); else LFK(false, false); }
 #undef LFK

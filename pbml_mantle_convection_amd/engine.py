@@ -884,8 +884,10 @@ class Engine:
         return p
 
     # -------------------------------------------------------------- backward
-    def backward(self, gout: torch.Tensor, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]):
-        """gout: d(loss)/d(output) [N, c_out, H', W'] f32.  Accumulates parameter gradients into `grads`."""
+    def backward(self, gout: torch.Tensor, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], gsum=None):
+        """gout: d(loss)/d(output) [N, c_out, H', W'] f32.  Accumulates parameter gradients into `grads`.
+        gsum: (per-block sums [N, blocks, 4] of gout's channel planes, blocks) from the producer of gout
+        (StokesLoss.gradient_sums()): the spatial means of gout are then taken from them instead of a pass over gout."""
         L.require_cuda(gout, "output gradient")
         gout = gout.contiguous().float()
         g, T, N = self.g, self.T, self.N
@@ -905,8 +907,11 @@ class Engine:
         fo = T[self.plan[-1]["node"].out]
         mean = None
         if g.subtract_mean:
-            L.call("mc_sum_hw", L.ptr(gout), N * g.c_out, self.out_h * self.out_w, 1.0 / (fo.H * fo.W),
-                   L.ptr(self.gmean), st)
+            if gsum is not None and g.c_out <= 4 and tuple(gsum[0].shape) == (N, gsum[1], 4):
+                L.call("mc_partial_sums_finalize", L.ptr(gsum[0]), N, gsum[1], g.c_out, 1.0 / (fo.H * fo.W), L.ptr(self.gmean), st)
+            else:
+                L.call("mc_sum_hw", L.ptr(gout), N * g.c_out, self.out_h * self.out_w, 1.0 / (fo.H * fo.W),
+                       L.ptr(self.gmean), st)
             mean = self.gmean
         gdst = (self.plan[-1]["dY"] if self.dy_per_layer else self.dYs[0]) if self.final_plain else self.dOut
         L.call("mc_pack_grad_nchw", L.ptr(gout), N, g.c_out, fo.H, fo.W, g.crop_w, L.ptr(mean), self.mc_gdtype,

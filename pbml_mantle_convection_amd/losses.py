@@ -58,6 +58,12 @@ class StokesLoss:
             self.cu, self.cv, self.cT = (torch.empty((N, H, W), **f32) for _ in range(3))
             self.gcu, self.gcv, self.gcT = (torch.empty((N, H, W), **f32) for _ in range(3))
             self.curl_ws = torch.empty(2 * N * (H - 2) * (W - 2), **f32)
+        self.gsum_blocks, self.gsum_part = 0, None
+        if self.fusable() and Cc <= 4:
+            # per-block spatial sums of the gradient planes (the adjoint of the network's mean subtraction takes its means
+            # from them: Engine.backward(gsum=...))
+            self.gsum_blocks = int(L.call("mc_loss_fused_blocks", N, H, W))
+            self.gsum_part = torch.zeros((N, self.gsum_blocks, 4), **f32)
         if self.lambda_mom != 0.0 and not self.fusable():         # (the one-launch form keeps S_x, S_y and eta in LDS)
             self.sx = torch.empty((N, H, W), **f32)
             self.sy = torch.empty((N, H, W), **f32)
@@ -69,6 +75,12 @@ class StokesLoss:
         if self.loss_type == "curl":
             return 1 + t + (1 if self.p_pred else 0)
         return 2 + t + (1 if self.p_pred else 0)
+
+    def gradient_sums(self):
+        """(per-block sums [N, blocks, 4], blocks) of the gradient planes written by the last evaluate(), or None."""
+        if getattr(self, "gsum_part", None) is None or not self.fusable():
+            return None
+        return self.gsum_part, self.gsum_blocks
 
     def fusable(self):
         """One-launch form (mc_loss_fused): the Unet branch without the curl head."""
@@ -124,7 +136,7 @@ class StokesLoss:
                 paras = paras.reshape(N, 3).float().contiguous()
                 scaler = scaler.reshape(N).float().contiguous()
             args = (L.ptr(uvp), L.ptr(self.mm), L.ptr(yc) if mom else None, L.ptr(paras) if mom else None,
-                    L.ptr(scaler) if mom else None, L.ptr(self.sums), gu, gv, gp, gT, Cc * HW, Cc * HW, st)
+                    L.ptr(scaler) if mom else None, L.ptr(self.sums), gu, gv, gp, gT, Cc * HW, Cc * HW, L.ptr(self.gsum_part), st)
             if cb8 is not None:
                 buf, mean, crop = cb8[:3]
                 L.call("mc_loss_fused", C.byref(d), None, None, None, None, 0, 0, L.ptr(buf), W + 2 * crop, crop, L.ptr(mean), Cc, *args)

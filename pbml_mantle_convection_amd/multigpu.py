@@ -87,6 +87,7 @@ def shard_range(n_items: int, world_size: int, rank: int):
     return int(per * rank), int(per * (rank + 1))
 
 
+GSUM_FROM_LOSS = os.environ.get("MANTLE_GSUM_FROM_LOSS", "1") != "0"   # spatial means of the loss gradient from the loss kernel's per-block sums
 CB8_LOSS = os.environ.get("MANTLE_CB8_LOSS", "1") != "0"     # the fused loss reads the network output in its CB8 layout (no NCHW copy)
 
 
@@ -276,7 +277,7 @@ class Trainer:
             out8, gy = loss.evaluate(y, uvp, yc, paras, scaler)
         if train:
             self.flat.grad.zero_()
-            eng.backward(gy, params, self.flat.views(self.flat.grad))
+            eng.backward(gy, params, self.flat.views(self.flat.grad), gsum=loss.gradient_sums() if GSUM_FROM_LOSS else None)
         return out8
 
     def _check_single_mesh(self, yc):

@@ -155,6 +155,30 @@ def test_one_launch_loss_equals_the_three_kernels(monkeypatch, H, W, p_pred, lam
     close(res["planes"][0], res["three"][0], atol=1e-7, rtol=1e-6, what="sums")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+def test_gradient_means_from_the_loss_kernel(monkeypatch, precision):
+    """The adjoint of the network's spatial-mean subtraction takes the means of the loss gradient from the loss kernel's
+    per-block sums (mc_partial_sums_finalize) instead of a pass over the gradient (mc_sum_hw): same flat gradient."""
+    from pbml_mantle_convection_amd import multigpu
+    from pbml_mantle_convection_amd.datasetio import synthetic_batch
+    from pbml_mantle_convection_amd.pytorch_networks_convae import Unet
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(multigpu, "GSUM_FROM_LOSS", on)
+        torch.manual_seed(5)
+        m = Unet(3, 10, 8, 4, torch.device(DEV), "gelu", "reflect", "mass", use_symm=True, repeats=2, f=5, p_pred=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[100], gamma=0.5)
+        tr = multigpu.Trainer(m, None, None, None, None, None, opt, sch, 0, 1, "/tmp/", p_pred=True, network="unet",
+                              loss_type="mass", lambda_mom=1e-6, precision=precision)
+        b = [t.to(DEV) for t in synthetic_batch(3, 48, 70, 11, p_pred=True, device="cpu")]
+        tr._fwd_bwd(b[0], b[1], b[4], b[3], b[2])
+        assert (tr.loss.gradient_sums() is not None)
+        grads.append(tr.flat.grad.clone())
+    rel = float((grads[0] - grads[1]).norm() / grads[1].norm())
+    assert rel < (1e-5 if precision == "fp32" else 2e-3), rel
+
+
 def test_fused_adam_matches_torch():
     from pbml_mantle_convection_amd import _lib as L
     n = 10007
