@@ -324,3 +324,38 @@ def test_unet_learned_padding_bf16_vs_golden(golden):
     num = sum(float((p.grad.double().cpu() - torch.from_numpy(g["grad/" + n]).double()).norm() ** 2) for n, p in m.named_parameters())
     den = sum(float(np.linalg.norm(g["grad/" + n].astype(np.float64)) ** 2) for n, _ in m.named_parameters())
     assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "mixed"])
+@pytest.mark.parametrize("c,sc,w,pad_w,mode", [
+    (10, 12, 26, 3, "reflect"),      # the benched input's shape class: 10 of 12 source channels, frame of 3
+    (10, 10, 30, 1, "replicate"),
+    (3, 3, 20, 2, "zeros"),
+    (8, 8, 16, 0, "reflect"),        # no frame at all
+    (10, 12, 21, 3, "reflect"),      # odd padded width
+])
+def test_input_pack_equals_padded_reference(dtype_name, c, sc, w, pad_w, mode):
+    """mc_pack_nchw (NCHW f32 -> CB8 with the width frame of the network input, per-channel scale) in the 16-bit layouts.
+    Every stored value must be the storage rounding of
+    scale * F.pad(x) — bit for bit (the conversion is one multiplication and one rounding)."""
+    import torch.nn.functional as F
+    from pbml_mantle_convection_amd import _lib as L
+    L.load()
+    mc = L.MC_BF16 if dtype_name == "bf16" else L.MC_MIX16
+    tdt = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(c * 100 + w)
+    N, H = 2, 5
+    x = torch.randn((N, sc, H, w), generator=g)
+    cs = torch.rand((c,), generator=g) + 0.5
+    xd, csd = x.to(DEV).contiguous(), cs.to(DEV).contiguous()
+    wp = w + 2 * pad_w
+    out = torch.full((N, (c + 7) // 8, H, wp, 8), float("nan"), dtype=tdt, device=DEV)
+    L.call("mc_pack_nchw", L.ptr(xd), N, c, sc, H, w, pad_w, L.PAD_MODES[mode], L.ptr(csd), mc, L.ptr(out), L.stream())
+    torch.cuda.synchronize()
+    ref = x[:, :c] * cs.view(1, c, 1, 1)
+    if pad_w:
+        ref = F.pad(ref, (pad_w, pad_w, 0, 0), mode={"zeros": "constant"}.get(mode, mode))
+    ref8 = torch.zeros((N, (c + 7) // 8 * 8, H, wp))
+    ref8[:, :c] = ref
+    ref_cb = ref8.view(N, -1, 8, H, wp).permute(0, 1, 3, 4, 2).to(tdt)
+    assert torch.equal(out.cpu().view(torch.int16), ref_cb.contiguous().view(torch.int16))
