@@ -4,7 +4,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", *sys.argv[3:],
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/tmp/_kr.o"] + (["-fno-slp-vectorize"] if "conv_rr" in src else [])
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
