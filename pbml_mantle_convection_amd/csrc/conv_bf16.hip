@@ -83,11 +83,16 @@ template <bool H16> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, 
 #endif
 // FUSE: 0 = plain; 1 = prologue (the sources are raw conv outputs: GroupNorm affine + activation applied while the tile
 // is staged); 2 = input-gradient epilogue (dz = dA * act'(z) and the GroupNorm-backward partial sums instead of dA).
-template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false, int FUSE = 0, bool H16 = false>
+// WN (wave columns): 1 = every wave owns MT M-tiles x all NT N-tiles of the block; 2 = the waves form a (WAVES / 2) x 2 grid,
+// a wave owns MT M-tiles x NT / 2 N-tiles.  With WN = 1 all four waves of a work-group fetch the SAME NT filter fragments
+// per K-step through the vector L1 (one 1 KB wave-load = 16 cycles of the CU's only address / L1 path: 8 resident waves x 4
+// fragments = 512 cycles per 12-MFMA step whose matrix-pipe share is 384; cycle stamps: 548); with WN = 2 a wave fetches half
+// of them for twice the pixels (2 fragments through the L1, 6 through LDS per 12 MFMAs).
+template <int K, int TH, int TW, int NT, int MT, bool OUT_F32 = false, int FUSE = 0, bool H16 = false, int WN = 1>
 #ifndef MC_CONV_WAVES
 #define MC_CONV_WAVES 2
 #endif
-__global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV_WAVES : 2)) void k_conv_mfma_bf16(
+__global__ __launch_bounds__(64 * (TH * (TW / 16) / MT) * WN, (MT * NT / WN <= 8 ? MC_CONV_WAVES : 2)) void k_conv_mfma_bf16(
     ConvGeom g, const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ bank,
     const float* __restrict__ bias, bf16_t* __restrict__ y0, bf16_t* __restrict__ y1, float* __restrict__ part,
     int n_groups, ConvFuse fz) {
@@ -95,8 +100,9 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   constexpr int PLANE = (TIH * TIW + 15) / 16 * 16;           // 16-byte slots per channel-block plane
   constexpr int STEPS = KSteps<K>::steps;
   constexpr int MTILES_X = TW / 16;
-  constexpr int WAVES = TH * MTILES_X / MT, NTHR = 64 * WAVES;   // each wave owns MT 16-pixel M-tiles of the output tile
-  static_assert(TH * MTILES_X == WAVES * MT && (WAVES == 4 || WAVES == 8), "tile / wave decomposition mismatch");
+  constexpr int WAVES = TH * MTILES_X / MT * WN, NTHR = 64 * WAVES;   // each wave owns MT 16-pixel M-tiles of the output tile
+  constexpr int NTW = NT / WN;                                         // ... and NTW of the block's NT N-tiles
+  static_assert(TH * MTILES_X * WN == WAVES * MT && NTW * WN == NT && (WAVES == 4 || WAVES == 8), "tile / wave decomposition mismatch");
   constexpr int IN_SLOTS = CHUNK_CB * PLANE;
   // NT == 1: the bank slice (13 KiB) is staged in LDS once per chunk.  NT > 1 (deep, channel-heavy layers): the slice
   // would be 27-53 KiB per chunk and re-staging it dominated the per-workgroup critical path, so B fragments are read
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar
   const int m = lane & 15, gq = lane >> 4;
   const int ntile0 = grp * NT;                                  // first global N-tile of this block
+  const int wm = wave / WN, nt_w0 = (wave % WN) * NTW;          // wave row; first in-block N-tile of this wave (scalars)
   const int ntiles_total = gridDim.y * NT;
   const int chunks = (g.CBin + CHUNK_CB - 1) / CHUNK_CB;
   const int items = g.N * g.tiles;
@@ -237,12 +244,12 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
   };
 
   // per-lane bias of its four output channels per N-tile
-  float bv[NT][4];
+  float bv[NTW][4];
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt)
+  for (int tt = 0; tt < NTW; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int co = (ntile0 + tt) * 16 + gq * 4 + r;
+      int co = (ntile0 + nt_w0 + tt) * 16 + gq * 4 + r;
       bv[tt][r] = (bias && co < g.Cout) ? bias[co] : 0.f;
     }
 
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 #define MC_PREFETCH_ALL 0
 #endif
   constexpr bool PREFETCH = (NT == 1) || MC_PREFETCH_ALL;
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NTW];
   if (PREFETCH && total_stages > 0) prefetch(0);
 #ifdef MC_EXP_STAMPS   /* timing experiment only */
   long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -269,33 +276,33 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = (f32x4){bv[tt][0], bv[tt][1], bv[tt][2], bv[tt][3]};   // bias folded in
+        for (int tt = 0; tt < NTW; ++tt) acc[i][tt] = (f32x4){bv[tt][0], bv[tt][1], bv[tt][2], bv[tt][3]};   // bias folded in
     }
     if (!PREFETCH) prefetch(t);
     MC_SYNC();                                            // LDS free: previous MFMA loop done
     STAMP(0);
     commit();
     if (!WGLOBAL && (chunks > 1 || t == 0)) stage_weights(ck);
-    const uint4* wglob = reinterpret_cast<const uint4*>(bank) + ((size_t)ck * STEPS * ntiles_total + ntile0) * 64 + lane;
+    const uint4* wglob = reinterpret_cast<const uint4*>(bank) + ((size_t)ck * STEPS * ntiles_total + ntile0 + nt_w0) * 64 + lane;
     STAMP(1);
     MC_SYNC();
     STAMP(2);
     if (PREFETCH && t + 1 < total_stages) prefetch(t + 1);      // in flight during the MFMA loop
     STAMP(3);
     // ---- MFMA loop (rolled over the K-steps: the per-lane operand offset is recomputed per step)
-    const int wbase = (wave * MT / MTILES_X) * TIW + ((wave * MT) % MTILES_X) * 16 + m;
+    const int wbase = (wm * MT / MTILES_X) * TIW + ((wm * MT) % MTILES_X) * 16 + m;
     // K loop, software pipelined: the fragments of step s+1 are read from LDS (MT + NT ds_read_b128 into their own
     // registers) while the MT*NT MFMAs of step s issue, so an MFMA never waits on the LDS read issued just before it.
     // This lane's (tap, channel-block) pair advances by 4 pairs = 2 taps per step: (ky, kx) is walked incrementally.
     int kx = gq >> 1, ky = 0;                                   // pair jp = 4 s + gq -> tap = jp / 2, cb = jp % 2
     const int cbk_off = (gq & 1) * PLANE + wbase;
-    auto load_frags = [&](int sidx, bf16x8 (&xf)[MT], bf16x8 (&wf)[NT]) {
+    auto load_frags = [&](int sidx, bf16x8 (&xf)[MT], bf16x8 (&wf)[NTW]) {
       const bool dummy = ky >= K;                               // pairs past k*k: weights are zero, any valid address
       const uint4* ap = in_s + (cbk_off + (dummy ? 0 : ky * TIW + kx));
       kx += 2;
       if (kx >= K) { kx -= K; ky += 1; }
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
+      for (int tt = 0; tt < NTW; ++tt) {
         if (WGLOBAL) {
 #ifdef MC_EXP_NOWLOAD   /* timing experiment only: wrong results */
           uint4 wv = make_uint4(sidx, tt, lane, 0);
@@ -311,17 +318,40 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
       for (int i = 0; i < MT; ++i)
         xf[i] = *reinterpret_cast<const bf16x8*>(ap + (i / MTILES_X) * TIW + (i % MTILES_X) * 16);
     };
-    auto do_mfma = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NT]) {
+    auto do_mfma = [&](const bf16x8 (&xf)[MT], const bf16x8 (&wf)[NTW]) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) acc[i][tt] = mfma16<(H16 && FUSE != 2)>(wf[tt], xf[i], acc[i][tt]);
+        for (int tt = 0; tt < NTW; ++tt) acc[i][tt] = mfma16<(H16 && FUSE != 2)>(wf[tt], xf[i], acc[i][tt]);
     };
 #ifndef MC_KPIPE
 #define MC_KPIPE 0
 #endif
-    if constexpr (WGLOBAL || MC_KPIPE == 2) {
-    bf16x8 xa[MT], xb[MT], wa[NT], wb[NT];
+#ifndef MC_KUNROLL
+#define MC_KUNROLL 1    /* 1: the K loop of the L2-fed configurations fully unrolled; 0: rolled by two steps (A/B) */
+#endif
+    if constexpr (WGLOBAL && MC_KUNROLL) {
+    // Fully unrolled: in the rolled form the fragment loads of the next step sit behind a loop-carried condition
+    // (s + 1 < STEPS), so the compiler cannot know how many loads are outstanding at the MFMAs and waits for ALL of them
+    // (s_waitcnt vmcnt(3..0) lgkmcnt(2..0) in front of the first MFMAs of every step: the loads issued one step ahead were
+    // waited for at once).  With static step indices every wait counts exactly the older set (vmcnt(7) lgkmcnt(5));
+    // sched_barrier keeps the sets in program order (the scheduler otherwise hoists every step's loads).  -0.08 ms per step.
+#ifndef MC_KDEPTH
+#define MC_KDEPTH 2     /* fragment sets in the ring: the loads of step s + MC_KDEPTH - 1 are issued before the MFMAs of step s (3, 4: +-0) */
+#endif
+    constexpr int KD = MC_KDEPTH;
+    bf16x8 xr[KD][MT], wr[KD][NTW];
+#pragma unroll
+    for (int s = 0; s < KD - 1 && s < STEPS; ++s) load_frags(s, xr[s], wr[s]);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s + KD - 1 < STEPS) load_frags(s + KD - 1, xr[(s + KD - 1) % KD], wr[(s + KD - 1) % KD]);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfma(xr[s % KD], wr[s % KD]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    } else if constexpr (WGLOBAL || MC_KPIPE == 2) {
+    bf16x8 xa[MT], xb[MT], wa[NTW], wb[NTW];
     load_frags(0, xa, wa);
 #pragma unroll 1
     for (int s = 0; s < STEPS; s += 2) {
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
       if (s + 1 < STEPS) do_mfma(xb, wb);
     }
     } else {
-    bf16x8 xa[MT], wa[NT];
+    bf16x8 xa[MT], wa[NTW];
 #pragma unroll 1
 #ifdef MC_EXP_NOK   /* timing experiment only */
     for (int s = 0; s < 1; ++s) {
@@ -342,11 +372,11 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
 #if MC_KPIPE == 1
       // all fragment reads of the step first, each into its own registers, then the MFMAs: an MFMA waits only for ITS
       // fragment (the default schedule reused one register quad and exposed the LDS latency before every MFMA)
-      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);
 #endif
       do_mfma(xa, wa);
 #if MC_KPIPE == 1
-      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);
 #endif
     }
     }
@@ -357,18 +387,18 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
     const int wi = bid + jitem * (int)gridDim.x;
     const int n = wi / g.tiles, tile = wi - n * g.tiles;
     const int ty0 = (tile / g.tiles_x) * TH, tx0 = (tile % g.tiles_x) * TW;
-    f32x2 s1[NT][2], s2[NT][2];                                  // per-lane (sum, sum of squares) of channel pairs
+    f32x2 s1[NTW][2], s2[NTW][2];                                // per-lane (sum, sum of squares) of channel pairs
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
+    for (int tt = 0; tt < NTW; ++tt)
 #pragma unroll
       for (int h = 0; h < 2; ++h) { s1[tt][h] = (f32x2){0.f, 0.f}; s2[tt][h] = (f32x2){0.f, 0.f}; }
     // output pointers of this lane's first M-tile per N-tile (bytes); later M-tiles are constant strides away
-    const int oy0 = ty0 + (wave * MT) / MTILES_X, ox0 = tx0 + ((wave * MT) % MTILES_X) * 16 + m;
-    char* dst0[NT];
-    bool cobok[NT];
+    const int oy0 = ty0 + (wm * MT) / MTILES_X, ox0 = tx0 + ((wm * MT) % MTILES_X) * 16 + m;
+    char* dst0[NTW];
+    bool cobok[NTW];
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      const int cob = (ntile0 + tt) * 2 + (gq >> 1);            // C/D: row = 4*(lane>>4)+reg = output channel
+    for (int tt = 0; tt < NTW; ++tt) {
+      const int cob = (ntile0 + nt_w0 + tt) * 2 + (gq >> 1);    // C/D: row = 4*(lane>>4)+reg = output channel
       cobok[tt] = cob < g.CBout;
       const int cbc = min(cob, g.CBout - 1);
       const int esz = OUT_F32 ? 4 : 2;
@@ -388,7 +418,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
         const bool inb = FULL || (oy < g.Ho && ox < g.Wo);
         const size_t off = (size_t)(i / MTILES_X) * row_bytes + (size_t)(i % MTILES_X) * 16 * 8 * (OUT_F32 ? 4 : 2);
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
+        for (int tt = 0; tt < NTW; ++tt) {
           const f32x2 v01 = (f32x2){acc[i][tt][0], acc[i][tt][1]}, v23 = (f32x2){acc[i][tt][2], acc[i][tt][3]};
           if (inb) {
             s1[tt][0] += v01; s1[tt][1] += v23;
@@ -421,8 +451,8 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
       const int CBe = g.CBout;                                    // channel blocks of the producer's output = ours
       const bf16_t* ey = reinterpret_cast<const bf16_t*>(fz.ey);
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        const int cob = (ntile0 + tt) * 2 + (gq >> 1);
+      for (int tt = 0; tt < NTW; ++tt) {
+        const int cob = (ntile0 + nt_w0 + tt) * 2 + (gq >> 1);
         const int cbc = min(cob, g.CBout - 1);
         // (scale, shift, mean, rstd) of this lane's four channels
         float csc[4], csh[4], cme[4], crs[4];
@@ -486,7 +516,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
       // sum over the 16 pixel lanes of each 16-lane group with a halving butterfly (8 shuffles for the 8 values of an
       // N-tile instead of 32): afterwards lane m of a group holds the group total of value index m >> 1 (m even)
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
+      for (int tt = 0; tt < NTW; ++tt) {
         float q8[8] = {s1[tt][0].x, s2[tt][0].x, s1[tt][0].y, s2[tt][0].y, s1[tt][1].x, s2[tt][1].x, s1[tt][1].y, s2[tt][1].y};
         const bool b3 = m & 8, b2 = m & 4, b1 = m & 2;
         float q4[4], q2[2], q1;
@@ -497,7 +527,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
         q1 = (b1 ? q2[1] : q2[0]) + __shfl_xor(b1 ? q2[0] : q2[1], 2, 64);
         q1 += __shfl_xor(q1, 1, 64);
         // value index = 4 b3 + 2 b2 + b1 = (channel r = idx >> 1, idx & 1 = sum / sum of squares)
-        if ((m & 1) == 0) red[wave][(tt * 16 + gq * 4) * 2 + (m >> 1)] = q1;
+        if ((m & 1) == 0) red[wave][((nt_w0 + tt) * 16 + gq * 4) * 2 + (m >> 1)] = q1;
       }
       MC_SYNC();
       if (threadIdx.x < NT * 32) {
@@ -505,7 +535,7 @@ __global__ __launch_bounds__(64 * (TH * (TW / 16) / MT), (MT * NT <= 8 ? MC_CONV
         if (co < g.CoutP) {
           float r = 0.f;
 #pragma unroll
-          for (int wv = 0; wv < WAVES; ++wv) r += red[wv][threadIdx.x];
+          for (int wv = 0; wv < WAVES / WN; ++wv) r += red[wv * WN + (int)(threadIdx.x >> 5) / NTW][threadIdx.x];   // the waves that own this N-tile
           part[(((size_t)n * (FUSE == 2 ? fz.estride : g.tiles) + tile) * g.CoutP + co) * 2 + (threadIdx.x & 1)] = r;
         }
       }
@@ -1003,27 +1033,33 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
   dim3 grid(bx, groups, 1);
   if (fuse == 2 && g.out_f32) return MC_EUNSUPPORTED;
   const bool h16 = fuse == 2 ? fz.ey16 != 0 : g.dtype == MC_MIX16;
-#define LAUNCH_H(K, TH, TW, NT, MT, F32, FU, H)                                                                        \
-  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT, F32, FU, H>), grid, dim3(64 * (TH * (TW / 16) / MT)), 0, s, g, \
+#define LAUNCH_H(K, TH, TW, NT, MT, F32, FU, H, WN)                                                                    \
+  hipLaunchKernelGGL((k_conv_mfma_bf16<K, TH, TW, NT, MT, F32, FU, H, WN>), grid, dim3(64 * (TH * (TW / 16) / (MT)) * (WN)), 0, s, g, \
                      (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)bank, bias, (bf16_t*)y0, (bf16_t*)y1, part,  \
                      groups, fz)
-#define LAUNCH_F(K, TH, TW, NT, MT, F32, FU)                                                                           \
-  do { if (h16) LAUNCH_H(K, TH, TW, NT, MT, F32, FU, true); else LAUNCH_H(K, TH, TW, NT, MT, F32, FU, false); } while (0)
-#define LAUNCH(K, TH, TW, NT, MT, F32)                                                                                 \
-  do { if (fuse == 0) LAUNCH_F(K, TH, TW, NT, MT, F32, 0); else if (fuse == 1) LAUNCH_F(K, TH, TW, NT, MT, F32, 1);   \
-       else LAUNCH_F(K, TH, TW, NT, MT, false, 2); } while (0)
+#define LAUNCH_F(K, TH, TW, NT, MT, F32, FU, WN)                                                                       \
+  do { if (h16) LAUNCH_H(K, TH, TW, NT, MT, F32, FU, true, WN); else LAUNCH_H(K, TH, TW, NT, MT, F32, FU, false, WN); } while (0)
+#define LAUNCH_W(K, TH, TW, NT, MT, F32, WN)                                                                           \
+  do { if (fuse == 0) LAUNCH_F(K, TH, TW, NT, MT, F32, 0, WN); else if (fuse == 1) LAUNCH_F(K, TH, TW, NT, MT, F32, 1, WN);   \
+       else LAUNCH_F(K, TH, TW, NT, MT, false, 2, WN); } while (0)
+#define LAUNCH(K, TH, TW, NT, MT, F32) LAUNCH_W(K, TH, TW, NT, MT, F32, 1)
+  // four N-tiles per block: the waves as a 2 x 2 grid (a wave owns twice the M-tiles and half of the N-tiles; see the kernel)
+  static const int wn2 = getenv("MC_CONV_WN") ? atoi(getenv("MC_CONV_WN")) : 2;
+#define LAUNCH4(K, TH, TW, MT) do { if (wn2 == 2) LAUNCH_W(K, TH, TW, 4, 2 * (MT), false, 2); else LAUNCH_W(K, TH, TW, 4, MT, false, 1); } while (0)
   if (g.out_f32) {
     if (g.K == 5) LAUNCH(5, 16, 32, 1, MC_NT1_MT, true); else if (g.K == 3) LAUNCH(3, 16, 32, 1, MC_NT1_MT, true); else return MC_EUNSUPPORTED;
   } else if (g.K == 5) {
     if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT, false);
-    else if (c.th == 12) { if (c.nt == 2) LAUNCH(5, 12, 16, 2, 3, false); else LAUNCH(5, 12, 16, 4, 3, false); }
-    else if (c.th == 8) { if (c.nt == 2) LAUNCH(5, 8, 16, 2, 2, false); else LAUNCH(5, 8, 16, 4, 2, false); }
-    else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH(5, 16, 16, 4, 4, false);
+    else if (c.th == 12) { if (c.nt == 2) LAUNCH(5, 12, 16, 2, 3, false); else LAUNCH4(5, 12, 16, 3); }
+    else if (c.th == 8) { if (c.nt == 2) LAUNCH(5, 8, 16, 2, 2, false); else LAUNCH4(5, 8, 16, 2); }
+    else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH4(5, 16, 16, 4);
   } else if (g.K == 3) {
-    if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4, false); else LAUNCH(3, 16, 16, 4, 4, false);
+    if (c.nt == 1) LAUNCH(3, 16, 32, 1, MC_NT1_MT, false); else if (c.nt == 2) LAUNCH(3, 16, 16, 2, 4, false); else LAUNCH4(3, 16, 16, 4);
   } else {
     return MC_EUNSUPPORTED;
   }
+#undef LAUNCH4
+#undef LAUNCH_W
 #undef LAUNCH
 #undef LAUNCH_F
 #undef LAUNCH_H
