@@ -971,6 +971,13 @@ inline Bf16Cfg cfg_for(int c_out, int k, int ho) {
   static const int th8 = getenv("MC_CONV_TH8") ? atoi(getenv("MC_CONV_TH8")) : 40;
   if (th8 && k == 5 && ho <= th8) return nt == 2 ? Bf16Cfg{8, 16, 2, 2} : Bf16Cfg{8, 16, 4, 2};
   if (nt == 2) return t12 ? Bf16Cfg{12, 16, 2, 3} : Bf16Cfg{16, 16, 2, 4};
+  // 24-row tiles, 6 x 4 accumulator tiles per wave (16 / 6 = 2.7 L1 cycles and 8 / 4 = 2 LDS cycles per MFMA against the 4
+  // cycles of CU time an MFMA has: the one configuration the matrix pipe bounds), where 24 rows cover the image as tightly as
+  // the 12 / 16-row choice (level 3 input gradients: 67 -> 72 rows): -0.03 ms per step.  MC_CONV_TH24 = largest row count.
+  // (The same tile for two-N-tile layers, 6 x 2 accumulators on 130 -> 144 rows: +0.02 ms.  The (24-row tiles ...) note below
+  // was measured before the K loop's waits were exact.)
+  static const int th24 = getenv("MC_CONV_TH24") ? atoi(getenv("MC_CONV_TH24")) : 80;
+  if (th24 && k == 5 && ho <= th24 && (ho + 23) / 24 * 24 <= (t12 ? (ho + 11) / 12 * 12 : (ho + 15) / 16 * 16)) return Bf16Cfg{24, 16, 4, 6};
   return t12 ? Bf16Cfg{12, 16, 4, 3} : Bf16Cfg{16, 16, 4, 4};
 }
 
@@ -1014,10 +1021,11 @@ int mc_bf16_pack(const ConvGeom& g, const float* w, int dgrad, void* packed, hip
 const char* mc_bf16_kernel_name(const ConvGeom& g) {
   Bf16Cfg c = cfg_for(g.Cout, g.K, g.Ho);
   if (g.out_f32) return g.K == 5 ? "k_conv_mfma_bf16<5,16,32,1,8,true>" : "k_conv_mfma_bf16<3,16,32,1,8,true>";
-  if (g.K == 5 && c.th == 12) return c.nt == 2 ? "k_conv_mfma_bf16<5,12,16,2,3,false>" : "k_conv_mfma_bf16<5,12,16,4,3,false>";
-  if (g.K == 5 && c.th == 8) return c.nt == 2 ? "k_conv_mfma_bf16<5,8,16,2,2,false>" : "k_conv_mfma_bf16<5,8,16,4,2,false>";
-  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4,false>" : "k_conv_mfma_bf16<5,16,16,4,4,false>");
-  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4,false>" : "k_conv_mfma_bf16<3,16,16,4,4,false>");
+  if (g.K == 5 && c.th == 24) return "k_conv_mfma_bf16<5,24,16,4,6,false>";
+  if (g.K == 5 && c.th == 12) return c.nt == 2 ? "k_conv_mfma_bf16<5,12,16,2,3,false>" : "k_conv_mfma_bf16<5,12,16,4,6,false,2x2>";
+  if (g.K == 5 && c.th == 8) return c.nt == 2 ? "k_conv_mfma_bf16<5,8,16,2,2,false>" : "k_conv_mfma_bf16<5,8,16,4,4,false,2x2>";
+  if (g.K == 5) return c.nt == 1 ? "k_conv_mfma_bf16<5,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<5,16,16,2,4,false>" : "k_conv_mfma_bf16<5,16,16,4,8,false,2x2>");
+  return c.nt == 1 ? "k_conv_mfma_bf16<3,16,32,1,8,false>" : (c.nt == 2 ? "k_conv_mfma_bf16<3,16,16,2,4,false>" : "k_conv_mfma_bf16<3,16,16,4,8,false,2x2>");
 }
 
 int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const void* bank, const float* bias, void* y0,
@@ -1050,6 +1058,7 @@ int mc_conv2d_bf16(const ConvGeom& g_in, const void* x0, const void* x1, const v
     if (g.K == 5) LAUNCH(5, 16, 32, 1, MC_NT1_MT, true); else if (g.K == 3) LAUNCH(3, 16, 32, 1, MC_NT1_MT, true); else return MC_EUNSUPPORTED;
   } else if (g.K == 5) {
     if (c.nt == 1) LAUNCH(5, 16, 32, 1, MC_NT1_MT, false);
+    else if (c.th == 24) LAUNCH_W(5, 24, 16, 4, 6, false, 1);
     else if (c.th == 12) { if (c.nt == 2) LAUNCH(5, 12, 16, 2, 3, false); else LAUNCH4(5, 12, 16, 3); }
     else if (c.th == 8) { if (c.nt == 2) LAUNCH(5, 8, 16, 2, 2, false); else LAUNCH4(5, 8, 16, 2); }
     else if (c.nt == 2) LAUNCH(5, 16, 16, 2, 4, false); else LAUNCH4(5, 16, 16, 4);
