@@ -719,7 +719,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_rr_bf16(ConvGeom g, const bf16_
 bool mc_rr_applies(int dtype, int cout, int wo, bool full_pad) {
   const int ntiles = (cout + 15) / 16;
   static const int on = [] { const char* e = getenv("MC_CONV_RR"); return e ? atoi(e) : 2; }();
-  static const int minw = [] { const char* e = getenv("MC_RR_MINW"); return e ? atoi(e) : 48; }();
+  // (48 until the wide-tile kernel's K loop and wave grid were fixed in round 3; with them the 63/64-wide level takes the
+  // wide-tile kernel: 100 vs 48 = -0.015 ... -0.03 ms in three same-box A/Bs, 200 = +-0)
+  static const int minw = [] { const char* e = getenv("MC_RR_MINW"); return e ? atoi(e) : 100; }();
   // launches with full padding (pad = k - 1: the input-gradient convolutions) run on a domain 2 (k - 1) pixels wider than
   // the layer: the 64-wide tiles then waste up to a whole tile column, which the wide-tile kernel's 16 / 32-wide tiles do not
   // (A/B on MI355X, CFG-3 step, mixed / bf16: 0: 12.16 / 10.74 ms, 140: 12.12 / 10.70, 270: 12.32 / 10.86, 520: 12.62 / 11.18)
